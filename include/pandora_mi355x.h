@@ -1,0 +1,185 @@
+/*
+ * pandora_mi355x.h — C-ABI of the MI355X (gfx950) kernels behind Open-Pandora's DDIM / 3-D U-Net
+ * denoising hot path.
+ *
+ * The reference (OpenSparseLLMs/Open-Pandora) has no FFI for this path: every op below replaces a
+ * PyTorch call site inside DynamiCrafter/lvdm (cited per entry point as file:line relative to the
+ * reference checkout).  The library is called through ctypes by open-pandora_amd/capi.py; PyTorch
+ * only owns the device memory and the stream.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (tensor.data_ptr()); tensors are dense in the documented
+ *     layout unless a leading dimension (ld*, in ELEMENTS) is given;
+ *   - activations are channels-last token matrices: [frames * H * W, C] row-major;
+ *   - dtype: PM_F16 (IEEE half) or PM_BF16 for activations and weights; accumulation, statistics,
+ *     biases and the DDIM latent are f32;
+ *   - no allocation, no synchronisation, no exceptions: work is enqueued on `stream`
+ *     (a hipStream_t passed as void*) and the call returns PM_OK (0) or a negative PM_E* code;
+ *   - re-entrant: no global mutable state.
+ */
+#ifndef PANDORA_MI355X_H
+#define PANDORA_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PM_OK 0
+#define PM_E_DTYPE (-1)   /* unsupported dtype code                                   */
+#define PM_E_SHAPE (-2)   /* shape / alignment precondition violated                  */
+#define PM_E_NULL (-3)    /* required pointer is NULL                                 */
+#define PM_E_LAUNCH (-4)  /* hipLaunchKernel reported an error                        */
+#define PM_E_WORKSPACE (-5) /* workspace too small                                    */
+
+#define PM_F16 1
+#define PM_BF16 2
+
+/* activation fused into a GEMM / conv epilogue */
+#define PM_ACT_NONE 0
+#define PM_ACT_SILU 1
+#define PM_ACT_GEGLU 2 /* weight rows interleaved x/gate in blocks of 16 (see pm_gemm) */
+
+const char* pm_strerror(int code);
+int pm_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * pm_gemm:  C[M, N] = epilogue(A[M, K] · W[N, K]^T)            (MFMA 16x16x32, f32 accumulate)
+ * replaces nn.Linear / 1x1 Conv call sites: attention.py:53-57,86-99,144 (to_q/k/v/out),
+ * :269,290,302,306 (proj_in/out), :336,362,374,405, :418-442 (GEGLU feed-forward),
+ * openaimodel3d.py:185-190 (1x1 skip_connection).
+ *   epilogue: + bias[n] (f32, may be NULL) -> act -> + residual[m, n] (may be NULL) -> store.
+ *   PM_ACT_GEGLU: W holds 2*Nout rows interleaved [16 value rows | 16 gate rows] per 32-row group,
+ *     bias likewise; C is [M, Nout] with Nout = N/2:  C = (v + bv) * gelu_erf(g + bg).
+ *   requirements: K % 64 == 0, lda/ldw % 8 == 0, 16-byte aligned bases; any M, N >= 1.
+ */
+int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+            const void* residual, int64_t ldr, void* C, int64_t ldc, int64_t M, int64_t N,
+            int64_t K, int act, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * pm_conv2d_3x3: implicit-GEMM 3x3 convolution, padding 1, on channels-last frames.
+ * replaces ResBlock in_layers[2] / out_layers[3] (openaimodel3d.py:157,182,221,232), the stem
+ * (:390), Downsample.op stride 2 (:68-70), Upsample nearest x2 + conv (:96,100-108) and out[2] (:549).
+ *   x: [F, H, W, Cin] (ldx = elements per pixel row, >= Cin);  Wp: packed [Cout, 9*Cin] with
+ *   k = (ky*3 + kx)*Cin + c;  y: [F, Ho, Wo, Cout] with Ho = H*up/stride (ceil), idem Wo.
+ *   upsample2x != 0: the conv reads a virtual (2H, 2W) nearest-neighbour image of x.
+ *   epilogue as pm_gemm (bias f32 [Cout]; residual [F*Ho*Wo, Cout] with ldr).
+ *   zero_page: >= 16 bytes of device zeros (source of padded taps).
+ */
+int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const float* bias,
+                  const void* residual, int64_t ldr, void* y, int64_t ldy, int64_t F, int64_t H,
+                  int64_t W, int64_t Cin, int64_t Cout, int stride, int upsample2x,
+                  const void* zero_page, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * pm_conv_temporal_k3: Conv3d kernel (3,1,1), padding (1,0,0) = 3-tap conv along the frame axis.
+ * replaces TemporalConvBlock.conv1..4 (openaimodel3d.py:258-269,275-282).
+ *   x: [F, P, Cin] frames of P = H*W pixels (ldx per pixel row); Wp: packed [Cout, 3*Cin] with
+ *   k = kt*Cin + c;  y: [F, P, Cout].  Frame f reads frames f-1, f, f+1.
+ *   halo_lo / halo_hi: optional [P, Cin] frames standing for frame -1 / frame F (frame-sharded
+ *   mode, same ldx); NULL means zero padding (clip boundary).
+ */
+int pm_conv_temporal_k3(const void* x, int64_t ldx, const void* halo_lo, const void* halo_hi,
+                        const void* Wp, const float* bias, const void* residual, int64_t ldr,
+                        void* y, int64_t ldy, int64_t F, int64_t P, int64_t Cin, int64_t Cout,
+                        const void* zero_page, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GroupNorm(32 groups) on channels-last data, optional fused SiLU.
+ * replaces GroupNormSpecific / nn.GroupNorm call sites: per-frame statistics (openaimodel3d.py:154-158,
+ * 178-183,546-550; attention.py:265,297) and (T,H,W) statistics (openaimodel3d.py:258-269;
+ * attention.py:331,368).
+ *   x: [NI, P, C]: NI independent instances (NI = frames for per-frame statistics, NI = 1 with
+ *   P = F*H*W for (T,H,W) statistics); C % 8 == 0, (C/8) <= 1024, C % groups == 0.
+ *   pm_groupnorm_stats writes partial {sum, sum of squares} per (instance, chunk, group) into
+ *   `partials` [NI, nchunks, groups, 2] f32; nchunks = pm_groupnorm_nchunks(P, C).
+ *   pm_groupnorm_apply reduces `partials` over nchunks in a fixed order (deterministic), then
+ *   y = (x - mean) * rstd * gamma + beta, optionally SiLU.  count = elements per group the
+ *   statistics were taken over (P * C/groups, or the all-rank total in frame-sharded mode).
+ */
+int64_t pm_groupnorm_nchunks(int64_t P, int64_t C);
+int pm_groupnorm_stats(const void* x, int64_t ldx, float* partials, int64_t NI, int64_t P,
+                       int64_t C, int groups, int dtype, void* stream);
+int pm_groupnorm_apply(const void* x, int64_t ldx, const float* partials, int64_t nchunks,
+                       const float* gamma, const float* beta, void* y, int64_t ldy, int64_t NI,
+                       int64_t P, int64_t C, int groups, double count, float eps, int silu,
+                       int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * pm_layernorm: LayerNorm over the last dimension; replaces BasicTransformerBlock.norm1/2/3
+ * (attention.py:225-227,243-245).  x, y: [M, C]; gamma, beta f32 [C]; C % 8 == 0, C <= 4096.
+ */
+int pm_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y,
+                 int64_t ldy, int64_t M, int64_t C, float eps, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * pm_attention: softmax(q k^T * scale) v with head dim 64, flash-style (no score matrix in HBM),
+ * up to two key/value segments that share q and are softmax-normalised independently:
+ *     out = attn(q, k1, v1) + w2 * attn(q, k2, v2)
+ * replaces CrossAttention.forward for the spatial self-attention (attention.py:101-125), the text
+ * + image cross-attention (:89-94,128-142) and CrossAttention.efficient_forward (:146-209).
+ *   q:  element (b, i, h, d) at q  + b*q_bs  + i*q_rs  + h*64 + d,   i < Nq
+ *   kX: element (b, j, h, d) at kX + b*kX_bs + j*kX_rs + h*64 + d,   j < NkX   (vX alike)
+ *   o:  same addressing as q with o_bs / o_rs.     strides in elements, multiples of 8;
+ *   a batch stride of 0 shares one key/value set between all b (text context).
+ *   k2 == NULL disables the second segment.
+ */
+int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const void* k1, const void* v1,
+                 int64_t k1_bs, int64_t k1_rs, int64_t Nk1, const void* k2, const void* v2,
+                 int64_t k2_bs, int64_t k2_rs, int64_t Nk2, float w2, void* o, int64_t o_bs,
+                 int64_t o_rs, int64_t B, int64_t heads, int64_t Nq, float scale, int dtype,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * pm_attention_temporal: self-attention over the frame axis at every pixel (head dim 64).
+ * replaces CrossAttention.forward as used by TemporalTransformer (attention.py:365-412; both attn1
+ * and attn2 are self-attention over T because only_self_att=True, :347-348,389-390).
+ *   q: [Fq, P, heads*64] (ldq per pixel row); k, v: [Fk, P, heads*64] (ldk); o like q (ldo).
+ *   Fq in {1,2,4,8,16} (local frames in frame-sharded mode), Fk <= 16.
+ */
+int pm_attention_temporal(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldk,
+                          void* o, int64_t ldo, int64_t Fq, int64_t Fk, int64_t P, int64_t heads,
+                          float scale, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * pm_gemv_f32: y[n] = act(sum_k W[n, k] * x[k] + bias[n]) with f32 x / y, 16-bit W.
+ * replaces the M = 1 linears on the embedding path: time_embed / fps_embedding
+ * (openaimodel3d.py:374-386,554-581) and every ResBlock.emb_layers (:171-177,222).
+ *   silu_in != 0 applies SiLU to x first (emb_layers[0]); act as PM_ACT_NONE / PM_ACT_SILU.
+ *   K % 8 == 0.
+ */
+int pm_gemv_f32(const void* W, int64_t ldw, const float* x, const float* bias, float* y,
+                int64_t N, int64_t K, int silu_in, int act, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * pm_ddim_update: one DDIM step of p_sample_ddim for the v-parameterisation, f32 latent.
+ * replaces ddim.py:238 (CFG combine), :243-245,271 + ddpm3d.py:235-247 (v -> eps, v -> x0),
+ * :273-277 (dynamic rescale), :282-288 (direction, noise, x_prev).
+ *   v = e_u + cfg * (e_c - e_u)   (e_u may be NULL: v = e_c)
+ *   eps = sqrt_ac * v + sqrt_1mac * x ;  x0 = (sqrt_ac * x - sqrt_1mac * v) * rescale
+ *   x_prev = sqrt_a_prev * x0 + dir_coef * eps + sigma * noise   (noise may be NULL when sigma == 0)
+ *   e_c / e_u are model outputs in `dtype`; x, noise, x_prev, pred_x0 are f32; n = element count.
+ */
+int pm_ddim_update(const float* x, const void* e_c, const void* e_u, const float* noise,
+                   float* x_prev, float* pred_x0, int64_t n, float cfg, float sqrt_ac,
+                   float sqrt_1mac, float rescale, float sqrt_a_prev, float dir_coef, float sigma,
+                   int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * layout helpers on the path boundary (DiffusionWrapper 'hybrid' concat ddpm3d.py:1077-1081 and the
+ * `b c t h w -> (b t) c h w` shuffles openaimodel3d.py:570,606):
+ *   pm_pack_input:  x f32 [C1, F, P] and cond f32 [C2, F, P]  ->  y dtype [F, P, C1 + C2]
+ *   pm_unpack_output: y dtype [F, P, C] -> out (dtype, same as the model) [C, F, P]
+ */
+int pm_pack_input(const float* x, const float* cond, void* y, int64_t C1, int64_t C2, int64_t F,
+                  int64_t P, int dtype, void* stream);
+int pm_unpack_output(const void* y, void* out, int64_t C, int64_t F, int64_t P, int dtype,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANDORA_MI355X_H */

@@ -1,0 +1,82 @@
+"""ctypes binding of libpandora_mi355x.so (include/pandora_mi355x.h).
+
+The product path has no fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpandora_mi355x.so")
+
+PM_F16, PM_BF16 = 1, 2
+PM_ACT_NONE, PM_ACT_SILU, PM_ACT_GEGLU = 0, 1, 2
+ACT_CODES = {"none": PM_ACT_NONE, None: PM_ACT_NONE, "silu": PM_ACT_SILU, "geglu": PM_ACT_GEGLU}
+
+# name -> (restype, argtypes); mirrors include/pandora_mi355x.h declaration by declaration
+SIGNATURES = {
+    "pm_strerror": (c_char_p, [c_int]),
+    "pm_abi_version": (c_int, []),
+    "pm_gemm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                        c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "pm_conv2d_3x3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                              c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
+                              c_void_p, c_int, c_void_p]),
+    "pm_conv_temporal_k3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                    c_int64, c_void_p, c_int, c_void_p]),
+    "pm_groupnorm_nchunks": (c_int64, [c_int64, c_int64]),
+    "pm_groupnorm_stats": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int,
+                                   c_int, c_void_p]),
+    "pm_groupnorm_apply": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                   c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_double,
+                                   c_float, c_int, c_int, c_void_p]),
+    "pm_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                             c_int64, c_float, c_int, c_void_p]),
+    "pm_attention": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64,
+                             c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float,
+                             c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int,
+                             c_void_p]),
+    "pm_attention_temporal": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                                      c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int,
+                                      c_void_p]),
+    "pm_gemv_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                            c_int, c_int, c_int, c_void_p]),
+    "pm_ddim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                               c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_int,
+                               c_void_p]),
+    "pm_pack_input": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                              c_int, c_void_p]),
+    "pm_unpack_output": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+class PandoraKernelError(RuntimeError):
+    pass
+
+
+def load(path=None):
+    """Load the shared library and attach the declared signatures. Raises if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise PandoraKernelError(
+            f"{path} not found: build it with `python open-pandora_amd/build.py` "
+            "(there is no CPU or PyTorch fallback for the denoising path)")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().pm_strerror(rc).decode()
+        raise PandoraKernelError(f"{what}: {msg} (code {rc})")

@@ -1,0 +1,97 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA, LDS).  gfx950 only: no portability
+// layers.  See include/pandora_mi355x.h for the C-ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pandora_mi355x.h"
+
+namespace pm {
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+template <typename T> struct Vec;
+template <> struct Vec<f16> {
+  typedef f16x8 v8;
+  typedef f16x4 v4;
+};
+template <> struct Vec<bf16> {
+  typedef bf16x8 v8;
+  typedef bf16x4 v4;
+};
+
+// 16-byte bag of eight 16-bit elements, reinterpretable as the MFMA operand vector.
+template <typename T> union Pack8 {
+  u32x4 u;
+  typename Vec<T>::v8 v;
+  T e[8];
+};
+template <typename T> union Pack4 {
+  u32x2 u;
+  typename Vec<T>::v4 v;
+  T e[4];
+};
+
+template <typename T> __device__ __forceinline__ float to_f32(T x) { return static_cast<float>(x); }
+template <typename T> __device__ __forceinline__ T from_f32(float x) { return static_cast<T>(x); }
+
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ u32x4 ld_global16(const void* p) {
+  return *reinterpret_cast<const u32x4*>(p);
+}
+__device__ __forceinline__ void st_global16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? PM_OK : PM_E_LAUNCH; }
+
+#define PM_DISPATCH_DTYPE(dtype, T, ...)  \
+  do {                                    \
+    if ((dtype) == PM_F16) {              \
+      typedef pm::f16 T;                  \
+      __VA_ARGS__;                        \
+    } else if ((dtype) == PM_BF16) {      \
+      typedef pm::bf16 T;                 \
+      __VA_ARGS__;                        \
+    } else {                              \
+      return PM_E_DTYPE;                  \
+    }                                     \
+  } while (0)
+
+}  // namespace pm

@@ -1,0 +1,160 @@
+// Small kernels on the edges of the path: f32 GEMV for the embedding MLPs, the fused DDIM update,
+// and the boundary layout conversions (NCTHW f32 latent <-> channels-last 16-bit activations).
+#include "common.hpp"
+
+namespace pm {
+
+// one wave per output row; K % 8 == 0
+template <typename T>
+__global__ __launch_bounds__(256) void gemv_kernel(const T* __restrict__ W, int64_t ldw,
+                                                   const float* __restrict__ x,
+                                                   const float* __restrict__ bias,
+                                                   float* __restrict__ y, int N, int K, int silu_in,
+                                                   int act) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const T* wp = W + (int64_t)n * ldw;
+  float acc = 0.f;
+  for (int k = lane * 8; k < K; k += 64 * 8) {
+    Pack8<T> w;
+    w.u = ld_global16(wp + k);
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + k);
+    const f32x4 x1 = *reinterpret_cast<const f32x4*>(x + k + 4);
+    float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xe = silu_in ? silu_f(xv[e]) : xv[e];
+      acc = fmaf(to_f32(w.e[e]), xe, acc);
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    float v = acc + (bias ? bias[n] : 0.f);
+    if (act == PM_ACT_SILU) v = silu_f(v);
+    y[n] = v;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ddim_kernel(const float* __restrict__ x,
+                                                   const T* __restrict__ e_c,
+                                                   const T* __restrict__ e_u,
+                                                   const float* __restrict__ noise,
+                                                   float* __restrict__ x_prev,
+                                                   float* __restrict__ pred_x0, int64_t n, float cfg,
+                                                   float sqrt_ac, float sqrt_1mac, float rescale,
+                                                   float sqrt_a_prev, float dir_coef, float sigma) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float ec = to_f32(e_c[i]);
+    float v = ec;
+    if (e_u != nullptr) {
+      const float eu = to_f32(e_u[i]);
+      v = eu + cfg * (ec - eu);
+    }
+    const float xi = x[i];
+    const float eps = sqrt_ac * v + sqrt_1mac * xi;
+    float x0 = sqrt_ac * xi - sqrt_1mac * v;
+    x0 *= rescale;
+    float xp = sqrt_a_prev * x0 + dir_coef * eps;
+    if (noise != nullptr) xp += sigma * noise[i];
+    x_prev[i] = xp;
+    if (pred_x0 != nullptr) pred_x0[i] = x0;
+  }
+}
+
+// y[f, p, c] = c < C1 ? x[c, f, p] : cond[c - C1, f, p]      (C1 + C2 is small: 8)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ cond,
+                                                         T* __restrict__ y, int C1, int C2,
+                                                         int64_t FP) {
+  const int C = C1 + C2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < FP; i += (int64_t)gridDim.x * 256) {
+    for (int c = 0; c < C; ++c) {
+      const float v = c < C1 ? x[(int64_t)c * FP + i] : cond[(int64_t)(c - C1) * FP + i];
+      y[i * C + c] = from_f32<T>(v);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_output_kernel(const T* __restrict__ y,
+                                                            T* __restrict__ out, int C,
+                                                            int64_t FP) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < FP; i += (int64_t)gridDim.x * 256)
+    for (int c = 0; c < C; ++c) out[(int64_t)c * FP + i] = y[i * C + c];
+}
+
+}  // namespace pm
+
+using namespace pm;
+
+extern "C" const char* pm_strerror(int code) {
+  switch (code) {
+    case PM_OK: return "ok";
+    case PM_E_DTYPE: return "unsupported dtype (want PM_F16 or PM_BF16)";
+    case PM_E_SHAPE: return "shape or alignment precondition violated";
+    case PM_E_NULL: return "required pointer is NULL";
+    case PM_E_LAUNCH: return "kernel launch failed";
+    case PM_E_WORKSPACE: return "workspace too small";
+    default: return "unknown error";
+  }
+}
+
+extern "C" int pm_abi_version(void) { return 1; }
+
+extern "C" int pm_gemv_f32(const void* W, int64_t ldw, const float* x, const float* bias, float* y,
+                           int64_t N, int64_t K, int silu_in, int act, int dtype, void* stream) {
+  if (!W || !x || !y) return PM_E_NULL;
+  if (N < 1 || K < 8 || (K & 7) || (ldw & 7) || ldw < K) return PM_E_SHAPE;
+  if (act != PM_ACT_NONE && act != PM_ACT_SILU) return PM_E_SHAPE;
+  dim3 grid((unsigned)((N + 3) / 4));
+  PM_DISPATCH_DTYPE(dtype, T,
+                    hipLaunchKernelGGL((gemv_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
+                                       (const T*)W, ldw, x, bias, y, (int)N, (int)K, silu_in, act);
+                    return check_launch());
+}
+
+extern "C" int pm_ddim_update(const float* x, const void* e_c, const void* e_u, const float* noise,
+                              float* x_prev, float* pred_x0, int64_t n, float cfg, float sqrt_ac,
+                              float sqrt_1mac, float rescale, float sqrt_a_prev, float dir_coef,
+                              float sigma, int dtype, void* stream) {
+  if (!x || !e_c || !x_prev) return PM_E_NULL;
+  if (n < 1) return PM_E_SHAPE;
+  if (sigma != 0.f && !noise) return PM_E_NULL;
+  int64_t nb = (n + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  PM_DISPATCH_DTYPE(dtype, T,
+                    hipLaunchKernelGGL((ddim_kernel<T>), dim3((unsigned)nb), dim3(256), 0,
+                                       (hipStream_t)stream, x, (const T*)e_c, (const T*)e_u, noise,
+                                       x_prev, pred_x0, n, cfg, sqrt_ac, sqrt_1mac, rescale,
+                                       sqrt_a_prev, dir_coef, sigma);
+                    return check_launch());
+}
+
+extern "C" int pm_pack_input(const float* x, const float* cond, void* y, int64_t C1, int64_t C2,
+                             int64_t F, int64_t P, int dtype, void* stream) {
+  if (!x || !y || (C2 > 0 && !cond)) return PM_E_NULL;
+  if (C1 < 1 || C2 < 0 || F < 1 || P < 1) return PM_E_SHAPE;
+  const int64_t FP = F * P;
+  int64_t nb = (FP + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  PM_DISPATCH_DTYPE(dtype, T,
+                    hipLaunchKernelGGL((pack_input_kernel<T>), dim3((unsigned)nb), dim3(256), 0,
+                                       (hipStream_t)stream, x, cond, (T*)y, (int)C1, (int)C2, FP);
+                    return check_launch());
+}
+
+extern "C" int pm_unpack_output(const void* y, void* out, int64_t C, int64_t F, int64_t P,
+                                int dtype, void* stream) {
+  if (!y || !out) return PM_E_NULL;
+  if (C < 1 || F < 1 || P < 1) return PM_E_SHAPE;
+  const int64_t FP = F * P;
+  int64_t nb = (FP + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  PM_DISPATCH_DTYPE(dtype, T,
+                    hipLaunchKernelGGL((unpack_output_kernel<T>), dim3((unsigned)nb), dim3(256), 0,
+                                       (hipStream_t)stream, (const T*)y, (T*)out, (int)C, FP);
+                    return check_launch());
+}

@@ -1,0 +1,221 @@
+"""HipOps: the op table of the denoising path, bound to the gfx950 C-ABI kernels.
+
+Every method takes/returns torch tensors that live on the GPU (PyTorch is only the allocator and
+the stream owner) and enqueues exactly one or two kernels from libpandora_mi355x.so on torch's
+current stream.  Activations are channels-last token matrices [frames*H*W, C] in f16 or bf16.
+There is deliberately no CPU / eager fallback here.
+"""
+import torch
+
+from . import capi
+
+_DT = {torch.float16: capi.PM_F16, torch.bfloat16: capi.PM_BF16}
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class HipOps:
+    name = "hip"
+
+    def __init__(self, dtype=torch.bfloat16, device="cuda"):
+        if dtype not in _DT:
+            raise ValueError(f"HipOps supports float16/bfloat16 activations, got {dtype}")
+        self.lib = capi.load()
+        self.dtype = dtype
+        self.dt = _DT[dtype]
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise capi.PandoraKernelError("HipOps needs a ROCm device (cuda:N)")
+        self.zero_page = torch.zeros(256, dtype=torch.uint8, device=self.device)
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _rows(self, t):
+        """(row stride in elements) of a 2-D, last-dim-contiguous view."""
+        assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == self.dtype, (t.shape, t.stride(), t.dtype)
+        return t.stride(0)
+
+    def empty(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or self.dtype, device=self.device)
+
+    # -- GEMM family -----------------------------------------------------------------------------
+    def gemm(self, a, w, bias=None, residual=None, act="none", out=None):
+        """out[M, N] = epi(a[M, K] @ w[N, K]^T); GEGLU halves N (weights pre-interleaved)."""
+        M, K = a.shape
+        N = w.shape[0]
+        assert w.shape[1] == K and w.is_contiguous() and w.dtype == self.dtype
+        n_out = N // 2 if act == "geglu" else N
+        if out is None:
+            out = self.empty(M, n_out)
+        rc = self.lib.pm_gemm(_ptr(a), self._rows(a), _ptr(w), K, _ptr(bias),
+                              _ptr(residual), self._rows(residual) if residual is not None else 0,
+                              _ptr(out), self._rows(out), M, N, K, capi.ACT_CODES[act], self.dt,
+                              self._stream())
+        capi.check(rc, f"pm_gemm M={M} N={N} K={K}")
+        return out
+
+    def conv3x3(self, x, wp, bias, F, H, W, stride=1, upsample=False, residual=None, out=None):
+        """x [F*H*W, Cin] -> [F*Ho*Wo, Cout]; wp packed [Cout, 9*Cin]."""
+        cin = x.shape[1]
+        cout = wp.shape[0]
+        assert x.shape[0] == F * H * W and wp.shape[1] == 9 * cin and wp.is_contiguous()
+        hv, wv = (2 * H, 2 * W) if upsample else (H, W)
+        ho, wo = (hv + stride - 1) // stride, (wv + stride - 1) // stride
+        if out is None:
+            out = self.empty(F * ho * wo, cout)
+        rc = self.lib.pm_conv2d_3x3(_ptr(x), self._rows(x), _ptr(wp), _ptr(bias), _ptr(residual),
+                                    self._rows(residual) if residual is not None else 0, _ptr(out),
+                                    self._rows(out), F, H, W, cin, cout, stride, int(upsample),
+                                    _ptr(self.zero_page), self.dt, self._stream())
+        capi.check(rc, f"pm_conv2d_3x3 F={F} H={H} W={W} Cin={cin} Cout={cout}")
+        return out
+
+    def conv_t3(self, x, wp, bias, F, P, residual=None, halo_lo=None, halo_hi=None, out=None):
+        """3-tap conv over frames: x [F*P, Cin] -> [F*P, Cout]; wp packed [Cout, 3*Cin]."""
+        cin = x.shape[1]
+        cout = wp.shape[0]
+        assert x.shape[0] == F * P and wp.shape[1] == 3 * cin and wp.is_contiguous()
+        for h in (halo_lo, halo_hi):
+            assert h is None or (h.shape == (P, cin) and self._rows(h) == self._rows(x))
+        if out is None:
+            out = self.empty(F * P, cout)
+        rc = self.lib.pm_conv_temporal_k3(_ptr(x), self._rows(x), _ptr(halo_lo), _ptr(halo_hi),
+                                          _ptr(wp), _ptr(bias), _ptr(residual),
+                                          self._rows(residual) if residual is not None else 0,
+                                          _ptr(out), self._rows(out), F, P, cin, cout,
+                                          _ptr(self.zero_page), self.dt, self._stream())
+        capi.check(rc, f"pm_conv_temporal_k3 F={F} P={P} Cin={cin} Cout={cout}")
+        return out
+
+    def gemv(self, w, x, bias=None, silu_in=False, act="none"):
+        """f32 y[N] = act(w[N, K] @ (silu?)(x[K]) + bias)."""
+        N, K = w.shape
+        assert x.dtype == torch.float32 and x.numel() == K and w.is_contiguous()
+        y = torch.empty(N, dtype=torch.float32, device=self.device)
+        rc = self.lib.pm_gemv_f32(_ptr(w), K, _ptr(x), _ptr(bias), _ptr(y), N, K, int(silu_in),
+                                  capi.ACT_CODES[act], self.dt, self._stream())
+        capi.check(rc, f"pm_gemv_f32 N={N} K={K}")
+        return y
+
+    # -- normalisation ---------------------------------------------------------------------------
+    def groupnorm_stats(self, x, NI, groups=32):
+        """partial {sum, sumsq}: f32 [NI, nchunks, groups, 2]."""
+        M, C = x.shape
+        P = M // NI
+        assert P * NI == M
+        nch = self.lib.pm_groupnorm_nchunks(P, C)
+        part = torch.empty(NI, nch, groups, 2, dtype=torch.float32, device=self.device)
+        rc = self.lib.pm_groupnorm_stats(_ptr(x), self._rows(x), _ptr(part), NI, P, C, groups,
+                                         self.dt, self._stream())
+        capi.check(rc, f"pm_groupnorm_stats NI={NI} P={P} C={C}")
+        return part
+
+    def groupnorm_apply(self, x, partials, gamma, beta, eps, NI, silu, count=None, groups=32, out=None):
+        M, C = x.shape
+        P = M // NI
+        if count is None:
+            count = float(P * (C // groups))
+        if out is None:
+            out = self.empty(M, C)
+        rc = self.lib.pm_groupnorm_apply(_ptr(x), self._rows(x), _ptr(partials), partials.shape[1],
+                                         _ptr(gamma), _ptr(beta), _ptr(out), self._rows(out), NI, P,
+                                         C, groups, float(count), float(eps), int(silu), self.dt,
+                                         self._stream())
+        capi.check(rc, f"pm_groupnorm_apply NI={NI} P={P} C={C}")
+        return out
+
+    def groupnorm(self, x, gamma, beta, eps, NI, silu, groups=32, stats_reduce=None, out=None):
+        """GroupNorm over NI instances of [P, C]; stats_reduce (frame-sharded mode) maps the partial
+        sums f32 [NI, groups, 2] to their all-rank totals and returns (totals, total_count)."""
+        part = self.groupnorm_stats(x, NI, groups)
+        count = None
+        if stats_reduce is not None:
+            tot, count = stats_reduce(part.sum(dim=1))
+            part = tot.reshape(NI, 1, groups, 2).contiguous()
+        return self.groupnorm_apply(x, part, gamma, beta, eps, NI, silu, count, groups, out)
+
+    def layernorm(self, x, gamma, beta, eps=1e-5, out=None):
+        M, C = x.shape
+        if out is None:
+            out = self.empty(M, C)
+        rc = self.lib.pm_layernorm(_ptr(x), self._rows(x), _ptr(gamma), _ptr(beta), _ptr(out),
+                                   self._rows(out), M, C, float(eps), self.dt, self._stream())
+        capi.check(rc, f"pm_layernorm M={M} C={C}")
+        return out
+
+    # -- attention -------------------------------------------------------------------------------
+    def attention(self, q, k1, v1, heads, k2=None, v2=None, w2=1.0, out=None):
+        """q [B, Nq, heads*64] view; kX/vX [B or 1, NkX, heads*64] views (last dim contiguous).
+        out = attn(q,k1,v1) + w2*attn(q,k2,v2), each softmax-normalised on its own."""
+        B, Nq, C = q.shape
+        assert C == heads * 64 and q.stride(2) == 1 and q.dtype == self.dtype
+
+        def kv(k, v):
+            assert k.shape == v.shape and k.stride() == v.stride() and k.stride(2) == 1
+            assert k.shape[0] in (1, B) and k.shape[2] == C
+            return (0 if k.shape[0] == 1 and B > 1 else k.stride(0)), k.stride(1), k.shape[1]
+
+        bs1, rs1, n1 = kv(k1, v1)
+        bs2 = rs2 = n2 = 0
+        if k2 is not None:
+            bs2, rs2, n2 = kv(k2, v2)
+        if out is None:
+            out = self.empty(B, Nq, C)
+        scale = 64 ** -0.5
+        rc = self.lib.pm_attention(_ptr(q), q.stride(0), q.stride(1), _ptr(k1), _ptr(v1), bs1, rs1,
+                                   n1, _ptr(k2), _ptr(v2), bs2, rs2, n2, float(w2), _ptr(out),
+                                   out.stride(0), out.stride(1), B, heads, Nq, scale, self.dt,
+                                   self._stream())
+        capi.check(rc, f"pm_attention B={B} heads={heads} Nq={Nq} Nk={n1}+{n2}")
+        return out
+
+    def attention_temporal(self, q, k, v, heads, out=None):
+        """q [Fq, P, heads*64], k/v [Fk, P, heads*64] views: attention over frames at each pixel."""
+        Fq, P, C = q.shape
+        Fk = k.shape[0]
+        assert C == heads * 64 and q.stride(2) == 1 and k.stride(2) == 1 and v.stride() == k.stride()
+        assert q.stride(0) == P * q.stride(1) and k.stride(0) == P * k.stride(1)
+        if out is None:
+            out = self.empty(Fq, P, C)
+        assert out.stride(0) == P * out.stride(1)
+        rc = self.lib.pm_attention_temporal(_ptr(q), q.stride(1), _ptr(k), _ptr(v), k.stride(1),
+                                            _ptr(out), out.stride(1), Fq, Fk, P, heads, 64 ** -0.5,
+                                            self.dt, self._stream())
+        capi.check(rc, f"pm_attention_temporal Fq={Fq} Fk={Fk} P={P} heads={heads}")
+        return out
+
+    # -- path boundary ---------------------------------------------------------------------------
+    def ddim_update(self, x, e_c, e_u, noise, cfg, sqrt_ac, sqrt_1mac, rescale, sqrt_a_prev,
+                    dir_coef, sigma, want_x0=True):
+        assert x.dtype == torch.float32 and x.is_contiguous() and e_c.is_contiguous()
+        x_prev = torch.empty_like(x)
+        x0 = torch.empty_like(x) if want_x0 else None
+        rc = self.lib.pm_ddim_update(_ptr(x), _ptr(e_c), _ptr(e_u), _ptr(noise), _ptr(x_prev),
+                                     _ptr(x0), x.numel(), float(cfg), float(sqrt_ac),
+                                     float(sqrt_1mac), float(rescale), float(sqrt_a_prev),
+                                     float(dir_coef), float(sigma), self.dt, self._stream())
+        capi.check(rc, "pm_ddim_update")
+        return x_prev, x0
+
+    def pack_input(self, x, cond):
+        """x f32 [C1, F, P], cond f32 [C2, F, P] -> [F*P, C1+C2] activations."""
+        C1, F, P = x.shape
+        C2 = 0 if cond is None else cond.shape[0]
+        assert x.dtype == torch.float32 and x.is_contiguous()
+        y = self.empty(F * P, C1 + C2)
+        rc = self.lib.pm_pack_input(_ptr(x), _ptr(cond), _ptr(y), C1, C2, F, P, self.dt, self._stream())
+        capi.check(rc, "pm_pack_input")
+        return y
+
+    def unpack_output(self, y, F, P):
+        """[F*P, C] -> [C, F, P] (same dtype)."""
+        C = y.shape[1]
+        assert y.is_contiguous()
+        out = self.empty(C, F, P)
+        rc = self.lib.pm_unpack_output(_ptr(y), _ptr(out), C, F, P, self.dt, self._stream())
+        capi.check(rc, "pm_unpack_output")
+        return out

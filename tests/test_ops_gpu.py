@@ -1,0 +1,285 @@
+"""GPU parity of every C-ABI kernel against the per-op oracle (oracle/ops_torch.py, f32 CPU math in
+the reference's own NCHW / einsum formulation).  Tolerances: norm-relative error <= 1e-3 for f16 I/O
+(the north-star bound), <= 4e-3 for bf16 I/O (bf16 output rounding alone is 2^-9 = 2e-3)."""
+import pytest
+import torch
+
+from oracle.ops_torch import TorchOps
+from open_pandora_amd import packing
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float16: 1e-3, torch.bfloat16: 4e-3}
+DTYPES = [torch.float16, torch.bfloat16]
+REF = TorchOps()
+
+
+def rel_err(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+def rnd(*shape, dtype, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def dev(*ts):
+    return [None if t is None else t.cuda() for t in ts]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (128, 128, 64), (1, 1280, 320), (77, 640, 1024),
+                                   (1000, 4, 128), (513, 2560, 640)])
+def test_gemm_bias_residual(hip_ops_factory, dtype, M, N, K):
+    ops = hip_ops_factory(dtype)
+    a, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=2)
+    bias = rnd(N, dtype=torch.float32, seed=3)
+    res = rnd(M, N, dtype=dtype, seed=4)
+    for use_b, use_r, act in [(False, False, "none"), (True, True, "none"), (True, False, "silu")]:
+        want = REF.gemm(a, w, bias if use_b else None, res if use_r else None, act)
+        da, dw, db, dr = dev(a, w, bias if use_b else None, res if use_r else None)
+        got = ops.gemm(da, dw, db, dr, act)
+        assert rel_err(got, want) <= TOL[dtype], (use_b, use_r, act)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_exact_integers(hip_ops_factory, dtype):
+    """Small-integer operands make every product and sum exact: any fragment-layout mistake
+    (row/col swap, k permutation) shows up as a mismatch, not as rounding."""
+    ops = hip_ops_factory(dtype)
+    g = torch.Generator().manual_seed(7)
+    M, N, K = 261, 200, 192
+    a = torch.randint(-3, 4, (M, K), generator=g).to(dtype)
+    w = torch.randint(-3, 4, (N, K), generator=g).to(dtype)
+    w[:, ::2] *= 0  # asymmetric sparsity pattern
+    want = a.float() @ w.float().t()
+    got = ops.gemm(a.cuda(), w.cuda())
+    assert torch.equal(got.float().cpu(), want.to(dtype).float())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_strided_views(hip_ops_factory, dtype):
+    """A, residual and the output may be column slices of wider row-major buffers (fused qkv,
+    zero-copy skip concat)."""
+    ops = hip_ops_factory(dtype)
+    M, N, K = 200, 320, 320
+    abuf = rnd(M, 3 * K, dtype=dtype, seed=1)
+    w = rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=2)
+    rbuf = rnd(M, 2 * N, dtype=dtype, seed=3)
+    obuf = torch.zeros(M, N + 64, dtype=dtype).cuda()
+    a, r = abuf[:, K:2 * K], rbuf[:, N:]
+    want = REF.gemm(a, w, None, r)
+    got = ops.gemm(abuf.cuda()[:, K:2 * K], w.cuda(), None, rbuf.cuda()[:, N:], out=obuf[:, 64:])
+    assert rel_err(got, want) <= TOL[dtype]
+    assert obuf[:, :64].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C", [(260, 320), (64, 1280), (129, 512)])
+def test_gemm_geglu(hip_ops_factory, dtype, M, C):
+    ops = hip_ops_factory(dtype)
+    w = rnd(8 * C, C, dtype=dtype, scale=C ** -0.5, seed=1)
+    b = rnd(8 * C, dtype=torch.float32, seed=2)
+    a = rnd(M, C, dtype=dtype, seed=3)
+    # reference formulation: proj -> chunk -> x * gelu(gate)   (attention.py:415-422)
+    y = a.float() @ w.float().t() + b
+    xv, gate = y.chunk(2, dim=-1)
+    want = xv * torch.nn.functional.gelu(gate)
+    wp, bp = packing.pack_geglu(w, b)
+    assert rel_err(REF.gemm(a, wp, bp, act="geglu"), want) < 1e-6  # the oracle's own packing
+    got = ops.gemm(a.cuda(), wp.cuda(), bp.cuda(), act="geglu")
+    assert got.shape == (M, 4 * C)
+    assert rel_err(got, want) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("F,H,W,Cin,Cout,stride,ups", [
+    (2, 9, 7, 8, 64, 1, False),      # stem-like: K = 72 (K tail inside a tile)
+    (3, 10, 16, 64, 72, 1, False),
+    (2, 10, 16, 128, 128, 2, False),  # Downsample
+    (2, 9, 7, 64, 64, 2, False),      # odd sizes, stride 2
+    (2, 5, 8, 64, 128, 1, True),      # Upsample (nearest x2 fused into the gather)
+    (1, 12, 12, 320, 4, 1, False),    # out conv: Cout = 4
+])
+def test_conv3x3(hip_ops_factory, dtype, F, H, W, Cin, Cout, stride, ups):
+    ops = hip_ops_factory(dtype)
+    x = rnd(F * H * W, Cin, dtype=dtype, seed=1)
+    w = rnd(Cout, Cin, 3, 3, dtype=dtype, scale=(9 * Cin) ** -0.5, seed=2)
+    bias = rnd(Cout, dtype=torch.float32, seed=3)
+    # independent reference: plain NCHW conv on the ORIGINAL weight layout
+    xi = x.float().reshape(F, H, W, Cin).permute(0, 3, 1, 2)
+    if ups:
+        xi = torch.nn.functional.interpolate(xi, scale_factor=2, mode="nearest")
+    yo = torch.nn.functional.conv2d(xi, w.float(), bias, stride=stride, padding=1)
+    want = yo.permute(0, 2, 3, 1).reshape(-1, Cout)
+    res = rnd(want.shape[0], Cout, dtype=dtype, seed=4)
+    wp = packing.pack_conv3x3(w)
+    assert rel_err(REF.conv3x3(x, wp, bias, F, H, W, stride, ups), want) < 1e-6
+    got = ops.conv3x3(x.cuda(), wp.cuda(), bias.cuda(), F, H, W, stride, ups, residual=res.cuda())
+    assert rel_err(got, want + res.float()) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("F,P,C,halo", [(16, 40, 64, False), (4, 77, 320, False), (2, 50, 128, True)])
+def test_conv_temporal(hip_ops_factory, dtype, F, P, C, halo):
+    ops = hip_ops_factory(dtype)
+    x = rnd(F * P, C, dtype=dtype, seed=1)
+    w = rnd(C, C, 3, 1, 1, dtype=dtype, scale=(3 * C) ** -0.5, seed=2)
+    bias = rnd(C, dtype=torch.float32, seed=3)
+    lo = rnd(P, C, dtype=dtype, seed=5) if halo else None
+    hi = rnd(P, C, dtype=dtype, seed=6) if halo else None
+    # independent reference: Conv3d on (b c t h w) with the ORIGINAL weight layout
+    xe = x.float().reshape(F, P, C)
+    if halo:
+        xe = torch.cat([lo.float()[None], xe, hi.float()[None]], 0)
+    xc = xe.permute(2, 0, 1)[None, :, :, :, None]
+    yo = torch.nn.functional.conv3d(xc, w.float(), bias, padding=(0 if halo else 1, 0, 0))
+    want = yo[0, :, :, :, 0].permute(1, 2, 0).reshape(F * P, C)
+    res = rnd(F * P, C, dtype=dtype, seed=4)
+    wp = packing.pack_conv_t3(w)
+    assert rel_err(REF.conv_t3(x, wp, bias, F, P, halo_lo=lo, halo_hi=hi), want) < 1e-6
+    dl, dh = dev(lo, hi)
+    got = ops.conv_t3(x.cuda(), wp.cuda(), bias.cuda(), F, P, residual=res.cuda(), halo_lo=dl, halo_hi=dh)
+    assert rel_err(got, want + res.float()) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("NI,P,C,silu,eps", [(16, 150, 320, True, 1e-5), (1, 2000, 320, True, 1e-5),
+                                             (4, 700, 64, False, 1e-6), (2, 33, 1920, True, 1e-5),
+                                             (1, 16 * 40, 2560, False, 1e-6)])
+def test_groupnorm(hip_ops_factory, dtype, NI, P, C, silu, eps):
+    ops = hip_ops_factory(dtype)
+    x = (rnd(NI * P, C, dtype=torch.float32, seed=1) * 2 + 0.7).to(dtype)
+    gamma = 1 + 0.2 * rnd(C, dtype=torch.float32, seed=2)
+    beta = 0.3 * rnd(C, dtype=torch.float32, seed=3)
+    want = REF.groupnorm(x, gamma, beta, eps, NI, silu)
+    got = ops.groupnorm(x.cuda(), gamma.cuda(), beta.cuda(), eps, NI, silu)
+    assert rel_err(got, want) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_groupnorm_external_stats(hip_ops_factory, dtype):
+    """Frame-sharded mode: two shards' partial sums combined == statistics over the whole clip."""
+    ops = hip_ops_factory(dtype)
+    P, C = 600, 320
+    x = (rnd(2 * P, C, dtype=torch.float32, seed=1) + 0.5).to(dtype)
+    gamma = 1 + 0.2 * rnd(C, dtype=torch.float32, seed=2)
+    beta = 0.3 * rnd(C, dtype=torch.float32, seed=3)
+    want = REF.groupnorm(x, gamma, beta, 1e-5, 1, True)
+    xs = [x[:P].cuda(), x[P:].cuda()]
+    parts = [ops.groupnorm_stats(t, 1).sum(dim=1) for t in xs]
+    total = (parts[0] + parts[1]).reshape(1, 1, 32, 2).contiguous()
+    count = 2 * P * (C // 32)
+    got = torch.cat([ops.groupnorm_apply(t, total, gamma.cuda(), beta.cuda(), 1e-5, 1, True, count)
+                     for t in xs], 0)
+    assert rel_err(got, want) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C", [(333, 320), (50, 1280), (7, 512), (100, 640)])
+def test_layernorm(hip_ops_factory, dtype, M, C):
+    ops = hip_ops_factory(dtype)
+    x = (rnd(M, C, dtype=torch.float32, seed=1) * 1.5 - 0.4).to(dtype)
+    gamma = 1 + 0.2 * rnd(C, dtype=torch.float32, seed=2)
+    beta = 0.3 * rnd(C, dtype=torch.float32, seed=3)
+    want = REF.layernorm(x, gamma, beta)
+    got = ops.layernorm(x.cuda(), gamma.cuda(), beta.cuda())
+    assert rel_err(got, want) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,heads,N", [(2, 2, 200), (1, 5, 640), (3, 1, 40), (2, 5, 2560)])
+def test_attention_self_fused_qkv(hip_ops_factory, dtype, B, heads, N):
+    """Self-attention reading q, k, v as column slices of one fused [B, N, 3C] projection."""
+    ops = hip_ops_factory(dtype)
+    C = heads * 64
+    qkv = rnd(B, N, 3 * C, dtype=dtype, scale=1.3, seed=1)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    want = REF.attention(q, k, v, heads)
+    d = qkv.cuda()
+    got = ops.attention(d[..., :C], d[..., C:2 * C], d[..., 2 * C:], heads)
+    assert rel_err(got, want) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_peaked_scores(hip_ops_factory, dtype):
+    """Force the running max to jump late: one key in the LAST tile dominates a few query rows."""
+    ops = hip_ops_factory(dtype)
+    B, heads, N = 1, 2, 300
+    C = heads * 64
+    q = rnd(B, N, C, dtype=torch.float32, seed=1)
+    k = rnd(B, N, C, dtype=torch.float32, seed=2)
+    v = rnd(B, N, C, dtype=torch.float32, seed=3)
+    k[0, 290] = 6 * q[0, 17]
+    k[0, 3] = 5 * q[0, 200]
+    q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
+    want = REF.attention(q, k, v, heads)
+    got = ops.attention(q.cuda(), k.cuda(), v.cuda(), heads)
+    assert rel_err(got, want) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,heads,N", [(16, 5, 160), (4, 20, 40)])
+def test_attention_cross_text_image(hip_ops_factory, dtype, B, heads, N):
+    """Text keys (77, shared by all frames: batch stride 0) + per-frame image keys (16)."""
+    ops = hip_ops_factory(dtype)
+    C = heads * 64
+    q = rnd(B, N, C, dtype=dtype, seed=1)
+    kt, vt = rnd(1, 77, C, dtype=dtype, seed=2), rnd(1, 77, C, dtype=dtype, seed=3)
+    ki, vi = rnd(B, 16, C, dtype=dtype, seed=4), rnd(B, 16, C, dtype=dtype, seed=5)
+    want = REF.attention(q, kt, vt, heads, ki, vi, 1.0)
+    dq, dkt, dvt, dki, dvi = dev(q, kt, vt, ki, vi)
+    got = ops.attention(dq, dkt, dvt, heads, dki, dvi, 1.0)
+    assert rel_err(got, want) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Fq,Fk,P,heads", [(16, 16, 37, 5), (2, 16, 50, 8), (16, 16, 640, 10)])
+def test_attention_temporal(hip_ops_factory, dtype, Fq, Fk, P, heads):
+    ops = hip_ops_factory(dtype)
+    C = heads * 64
+    qkv = rnd(Fk, P, 3 * C, dtype=dtype, scale=1.2, seed=1)
+    q, k, v = qkv[:Fq, :, :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    want = REF.attention_temporal(q, k, v, heads)
+    d = qkv.cuda()
+    got = ops.attention_temporal(d[:Fq, :, :C], d[..., C:2 * C], d[..., 2 * C:], heads)
+    assert rel_err(got, want) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemv(hip_ops_factory, dtype):
+    ops = hip_ops_factory(dtype)
+    w = rnd(1000, 1280, dtype=dtype, scale=1280 ** -0.5, seed=1)
+    x, b = rnd(1280, dtype=torch.float32, seed=2), rnd(1000, dtype=torch.float32, seed=3)
+    for silu_in, act in [(False, "none"), (True, "none"), (False, "silu")]:
+        want = REF.gemv(w, x, b, silu_in, act)
+        got = ops.gemv(w.cuda(), x.cuda(), b.cuda(), silu_in, act)
+        assert rel_err(got, want) <= 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_ddim_update_and_layout(hip_ops_factory, dtype):
+    ops = hip_ops_factory(dtype)
+    C, F, P = 4, 16, 60
+    x = rnd(C, F, P, dtype=torch.float32, seed=1)
+    cond = rnd(C, F, P, dtype=torch.float32, seed=2)
+    ec, eu = rnd(C, F, P, dtype=dtype, seed=3), rnd(C, F, P, dtype=dtype, seed=4)
+    noise = rnd(C, F, P, dtype=torch.float32, seed=5)
+    args = (4.0, 0.83, 0.55, 0.97, 0.9, 0.31, 0.2)
+    want_p, want_0 = REF.ddim_update(x, ec, eu, noise, *args)
+    got_p, got_0 = ops.ddim_update(x.cuda(), ec.cuda(), eu.cuda(), noise.cuda(), *args)
+    assert rel_err(got_p, want_p) <= 1e-6 and rel_err(got_0, want_0) <= 1e-6
+    packed = ops.pack_input(x.cuda(), cond.cuda())
+    assert torch.equal(packed.cpu(), REF.pack_input(x, cond).to(dtype))
+    y = rnd(F * P, C, dtype=dtype, seed=6)
+    assert torch.equal(ops.unpack_output(y.cuda(), F, P).cpu(), REF.unpack_output(y, F, P))
+
+
+def test_bad_arguments_raise(hip_ops_factory):
+    from open_pandora_amd.capi import PandoraKernelError
+    ops = hip_ops_factory(torch.float16)
+    a = torch.zeros(16, 72, dtype=torch.float16).cuda()  # K = 72 is not a multiple of 64
+    w = torch.zeros(8, 72, dtype=torch.float16).cuda()
+    with pytest.raises(PandoraKernelError):
+        ops.gemm(a, w)
