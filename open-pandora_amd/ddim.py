@@ -1,0 +1,182 @@
+"""DDIMSampler: the S-step denoising loop of the hot path (drop-in for
+lvdm.models.samplers.ddim.DDIMSampler, ddim.py:10-290).
+
+Same call surface: `DDIMSampler(model).sample(S, batch_size, shape, conditioning, ..., eta, x_T,
+unconditional_guidance_scale, unconditional_conditioning, precision, fs, timestep_spacing,
+guidance_rescale, **kwargs)` -> (samples, intermediates), including the gradio progress kwargs
+(`gr_progress_bar`, `round_info`, ddim.py:171-176).  Differences underneath:
+
+* the latent stays f32 on the device for the whole loop; per step the two U-Net outputs, the CFG
+  combine, v->eps / v->x0, dynamic rescale and the x_{t-1} update are ONE fused kernel
+  (pm_ddim_update) instead of ~10 elementwise launches (ddim.py:238-288);
+* all per-step scalars are computed once on the host with the reference's exact arithmetic
+  (bf16-quantised tables, f64 sigmas cast to f32, f32 `1 - a_prev - sigma^2`), so the reference's
+  numerics quirks are reproduced, including the NaN of S=10 / eta=1 / 'uniform_trailing' (SURVEY §0.5);
+* noise comes from an injectable `noise_fn(step_index, shape) -> f32 tensor` (default: torch.randn
+  on the device), so both sides of a parity run can consume the same draws.
+"""
+import numpy as np
+import torch
+
+
+
+def make_ddim_timesteps(method, num_ddim, num_ddpm):
+    """utils_diffusion.py:56-76."""
+    if method == "uniform":
+        c = num_ddpm // num_ddim
+        return np.asarray(list(range(0, num_ddpm, c))) + 1
+    if method == "uniform_trailing":
+        c = num_ddpm / num_ddim
+        return np.flip(np.round(np.arange(num_ddpm, 0, -c))).astype(np.int64) - 1
+    if method == "quad":
+        return ((np.linspace(0, np.sqrt(num_ddpm * 0.8), num_ddim)) ** 2).astype(int) + 1
+    raise NotImplementedError(f'There is no ddim discretization method called "{method}"')
+
+
+class DDIMSampler:
+    def __init__(self, model, schedule="linear", **kwargs):
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+        self.counter = 0
+
+    def _ops(self):
+        ops = getattr(self.model, "ops", None)
+        if ops is None:
+            ops = self.model.model.diffusion_model.ops
+        if ops is None:
+            raise RuntimeError("the U-Net has no op table bound (UNetModel.bind(HipOps(...)))")
+        return ops
+
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0.0, verbose=True):
+        """Per-step scalar tables (ddim.py:24-63 + utils_diffusion.py:79-91), kept on the host."""
+        m = self.model
+        ts = make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps)
+        self.ddim_timesteps = ts
+        ac32 = m.alphas_cumprod.detach().to(torch.float32).cpu()  # bf16-quantised values, as f32
+        assert ac32.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
+        idx = torch.as_tensor(np.ascontiguousarray(ts), dtype=torch.long)
+        a = ac32[idx].to(torch.float64)
+        a_prev = torch.cat([ac32[0:1], ac32[idx[:-1]]]).to(torch.float64)
+        # reference: float64 array/tensor arithmetic, then cast to the latent dtype per step
+        sig = ddim_eta * torch.sqrt((1 - a_prev) / (1 - a) * (1 - a / a_prev))
+        self.ddim_alphas = a.to(torch.float32)
+        self.ddim_alphas_prev = a_prev.numpy()
+        self.ddim_sigmas = sig
+        self.ddim_sqrt_one_minus_alphas = torch.sqrt(1.0 - self.ddim_alphas)
+        if m.use_dynamic_rescale:
+            sa = m.scale_arr.detach().cpu()[idx]
+            self.ddim_scale_arr = sa
+            self.ddim_scale_arr_prev = torch.cat([sa[0:1], sa[:-1]])
+        self._sqrt_ac = m.sqrt_alphas_cumprod.detach().to(torch.float32).cpu().numpy()
+        self._sqrt_1mac = m.sqrt_one_minus_alphas_cumprod.detach().to(torch.float32).cpu().numpy()
+
+    def step_scalars(self, index, step):
+        """f32 scalars of p_sample_ddim (ddim.py:252-288) for the v-parameterisation."""
+        f32 = np.float32
+        a_prev = f32(self.ddim_alphas_prev[index])
+        sigma = f32(self.ddim_sigmas[index].item())
+        with np.errstate(invalid="ignore"):
+            dir_coef = np.sqrt(f32(f32(1.0) - a_prev) - f32(sigma * sigma), dtype=f32)
+        rescale = f32(1.0)
+        if self.model.use_dynamic_rescale:
+            rescale = f32(self.ddim_scale_arr_prev[index].item()) / f32(self.ddim_scale_arr[index].item())
+        return dict(sqrt_ac=float(self._sqrt_ac[step]), sqrt_1mac=float(self._sqrt_1mac[step]),
+                    rescale=float(rescale), sqrt_a_prev=float(np.sqrt(a_prev, dtype=f32)),
+                    dir_coef=float(dir_coef), sigma=float(sigma))
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None,
+               img_callback=None, quantize_x0=False, eta=0.0, mask=None, x0=None, temperature=1.0,
+               noise_dropout=0.0, score_corrector=None, corrector_kwargs=None, verbose=True,
+               schedule_verbose=False, x_T=None, log_every_t=100, unconditional_guidance_scale=1.0,
+               unconditional_conditioning=None, precision=None, fs=None, timestep_spacing="uniform",
+               guidance_rescale=0.0, **kwargs):
+        if conditioning is not None and isinstance(conditioning, dict):
+            first = conditioning[list(conditioning.keys())[0]]
+            cbs = (first[0] if isinstance(first, (list, tuple)) else first).shape[0]
+            if cbs != batch_size:
+                print(f"Warning: Got {cbs} conditionings but batch-size is {batch_size}")
+        for flag, name in ((quantize_x0, "quantize_x0"), (score_corrector is not None, "score_corrector"),
+                           (noise_dropout > 0.0, "noise_dropout"), (guidance_rescale > 0.0, "guidance_rescale")):
+            if flag:
+                raise NotImplementedError(f"{name} is not on the Open-Pandora generate() path")
+        self.make_schedule(ddim_num_steps=S, ddim_discretize=timestep_spacing, ddim_eta=eta, verbose=schedule_verbose)
+        size = (batch_size, *shape)
+        return self.ddim_sampling(conditioning, size, callback=callback, img_callback=img_callback, mask=mask,
+                                  x0=x0, temperature=temperature, x_T=x_T, log_every_t=log_every_t,
+                                  unconditional_guidance_scale=unconditional_guidance_scale,
+                                  unconditional_conditioning=unconditional_conditioning, verbose=verbose,
+                                  precision=precision, fs=fs, **kwargs)
+
+    @torch.no_grad()
+    def p_sample_ddim(self, x, c, t, index, temperature=1.0, unconditional_guidance_scale=1.0,
+                      unconditional_conditioning=None, fs=None, noise=None, want_x0=True, step=None, **kwargs):
+        """One denoising step (ddim.py:218-290): two U-Net forwards when CFG is on, then the fused
+        update kernel.  `t` is the (b,) long tensor of the current DDPM timestep, `index` its position
+        in the DDIM schedule.  `noise` (f32, x-shaped) overrides the device RNG draw."""
+        ops = self._ops()
+        if step is None:
+            step = int(t[0])  # device sync; ddim_sampling passes the host-side value instead
+        use_cfg = unconditional_conditioning is not None and unconditional_guidance_scale != 1.0
+        e_c = self.model.apply_model(x, t, c, fs=fs, **kwargs)
+        e_u = self.model.apply_model(x, t, unconditional_conditioning, fs=fs, **kwargs) if use_cfg else None
+        sc = self.step_scalars(index, step)
+        if sc["sigma"] != 0.0:
+            if noise is None:
+                noise = torch.randn(x.shape, device=ops.device)
+            noise = noise.to(device=ops.device, dtype=torch.float32).contiguous()
+            sc["sigma"] *= float(temperature)
+        else:
+            noise = None
+        return ops.ddim_update(x, e_c.contiguous(), None if e_u is None else e_u.contiguous(), noise,
+                               float(unconditional_guidance_scale), want_x0=want_x0, **sc)
+
+    @torch.no_grad()
+    def ddim_sampling(self, cond, shape, x_T=None, callback=None, mask=None, x0=None, img_callback=None,
+                      log_every_t=100, temperature=1.0, unconditional_guidance_scale=1.0,
+                      unconditional_conditioning=None, verbose=True, precision=None, fs=None,
+                      noise_fn=None, **kwargs):
+        ops = self._ops()
+        device = ops.device
+        img = torch.randn(shape, device=device) if x_T is None else x_T.to(device)
+        img = img.to(torch.float32).contiguous()  # the loop state stays f32 (see module docstring)
+        timesteps = self.ddim_timesteps
+        total_steps = timesteps.shape[0]
+        time_range = np.flip(timesteps)
+        intermediates = {"x_inter": [img], "pred_x0": [img]}
+        if kwargs.get("gr_progress_bar") is not None:
+            ri = kwargs.get("round_info", [1, 1])
+            iterator = kwargs["gr_progress_bar"].tqdm(time_range, desc=f"DDIM Sampler (Round {ri[0]}/{ri[1]})", total=total_steps)
+        elif verbose:
+            from tqdm import tqdm
+            iterator = tqdm(time_range, desc="DDIM Sampler", total=total_steps)
+        else:
+            iterator = time_range
+        clean_cond = kwargs.pop("clean_cond", False)
+        model_kwargs = {k: v for k, v in kwargs.items()
+                        if k not in ("gr_progress_bar", "round_info", "cfg_img", "unconditional_conditioning_img_nonetext")}
+        b = shape[0]
+        for i, step in enumerate(iterator):
+            index = total_steps - i - 1
+            step = int(step)
+            ts = torch.full((b,), step, device=device, dtype=torch.long)
+            if mask is not None:  # blend with the (noised) original latent, ddim.py:186-192
+                assert x0 is not None
+                img_orig = x0 if clean_cond else self.model.q_sample(x0, ts.cpu()).to(device)
+                img = (img_orig * mask + (1.0 - mask) * img).float().contiguous()
+            img, pred_x0 = self.p_sample_ddim(img, cond, ts, index, temperature=temperature,
+                                              unconditional_guidance_scale=unconditional_guidance_scale,
+                                              unconditional_conditioning=unconditional_conditioning, fs=fs,
+                                              noise=noise_fn(i, shape) if noise_fn is not None else None, step=step,
+                                              **model_kwargs)
+            if callback:
+                callback(i)
+            if img_callback:
+                img_callback(pred_x0, i)
+            if index % log_every_t == 0 or index == total_steps - 1:
+                intermediates["x_inter"].append(img)
+                intermediates["pred_x0"].append(pred_x0)
+        if precision is not None and isinstance(precision, torch.dtype):
+            img = img.to(precision)
+        return img, intermediates

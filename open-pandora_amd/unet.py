@@ -1,0 +1,489 @@
+"""UNetModel: MI355X-native drop-in for lvdm.modules.networks.openaimodel3d.UNetModel.
+
+Same constructor keywords (openaimodel3d.py:314-345), same `forward(x, timesteps, context,
+features_adapter, fs, **kwargs)` (:552) and an identical state_dict key set / shapes (SURVEY §2.4,
+including the reference's `temopral_conv` spelling), so checkpoints and the YAML `target:` seam
+(inference_512_v1.0.yaml:24-25) carry over.  What differs is everything underneath:
+
+* activations never exist as NCHW: they are channels-last token matrices [frames*H*W, C], which makes
+  every Linear a plain GEMM, every 3x3 / temporal conv an implicit GEMM, and removes all the
+  `(b f) c h w <-> b c f h w` shuffles around the temporal modules (openaimodel3d.py:36-48);
+* every op goes through an op table (`self.ops`): `HipOps` (gfx950 kernels over the C-ABI) in
+  production.  nn.Module parameters are only the reference-format storage; `prepare()` builds the
+  kernel-side packed copies (fused qkv, tap-major conv weights, interleaved GEGLU rows).
+* `fp` (a FrameParallel object, optional) supplies the three cross-frame exchanges when the frame
+  axis is sharded over ranks: (T,H,W) GroupNorm statistics, temporal-conv halos, temporal K/V.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import packing
+
+
+def _unsupported(flag, name):
+    if flag:
+        raise NotImplementedError(f"{name} is not used by the shipped Open-Pandora configs and is not built")
+
+
+def timestep_embedding(timesteps, dim, max_period=10000):
+    """Sinusoidal embedding with the reference's bf16-quantised frequency table
+    (utils_diffusion.py:8-28: `torch.arange(..., dtype=torch.bfloat16)` feeds the exp)."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.bfloat16) / half)
+    args = timesteps[:, None].float() * freqs.to(timesteps.device)[None].float()
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers: same attribute names / child indices as the reference modules
+# ------------------------------------------------------------------------------------------------
+class CrossAttention(nn.Module):
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, image_cross_attention=False):
+        super().__init__()
+        assert dim_head == 64, "the attention kernels are specialised for head dim 64"
+        inner = heads * dim_head
+        self.heads = heads
+        self.self_attn = context_dim is None
+        context_dim = context_dim or query_dim
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_k = nn.Linear(context_dim, inner, bias=False)
+        self.to_v = nn.Linear(context_dim, inner, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(0.0))
+        self.image_cross_attention = image_cross_attention
+        if image_cross_attention:
+            self.to_k_ip = nn.Linear(context_dim, inner, bias=False)
+            self.to_v_ip = nn.Linear(context_dim, inner, bias=False)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.Sequential(GEGLU(dim, dim * mult), nn.Dropout(0.0), nn.Linear(dim * mult, dim))
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, n_heads, d_head, context_dim=None, image_cross_attention=False):
+        super().__init__()
+        self.attn1 = CrossAttention(dim, None, n_heads, d_head)
+        self.ff = FeedForward(dim)
+        self.attn2 = CrossAttention(dim, context_dim, n_heads, d_head, image_cross_attention)
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.norm3 = nn.LayerNorm(dim)
+
+
+class _Transformer(nn.Module):
+    def __init__(self, in_channels, n_heads, d_head, context_dim, use_linear, image_cross_attention, conv1d):
+        super().__init__()
+        inner = n_heads * d_head
+        self.in_channels, self.inner, self.heads = in_channels, inner, n_heads
+        self.norm = nn.GroupNorm(32, in_channels, eps=1e-6, affine=True)
+        if use_linear:
+            self.proj_in = nn.Linear(in_channels, inner)
+        elif conv1d:
+            self.proj_in = nn.Conv1d(in_channels, inner, kernel_size=1)
+        else:
+            self.proj_in = nn.Conv2d(in_channels, inner, kernel_size=1)
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(inner, n_heads, d_head, context_dim, image_cross_attention)])
+        if use_linear:
+            self.proj_out = nn.Linear(inner, in_channels)
+        elif conv1d:
+            self.proj_out = nn.Conv1d(inner, in_channels, kernel_size=1)
+        else:
+            self.proj_out = nn.Conv2d(inner, in_channels, kernel_size=1)
+        for p in self.proj_out.parameters():  # zero_module (attention.py:288-290,360-362)
+            nn.init.zeros_(p)
+
+
+class SpatialTransformer(_Transformer):
+    def __init__(self, in_channels, n_heads, d_head, context_dim, use_linear, image_cross_attention):
+        super().__init__(in_channels, n_heads, d_head, context_dim, use_linear, image_cross_attention, False)
+
+
+class TemporalTransformer(_Transformer):
+    def __init__(self, in_channels, n_heads, d_head, use_linear):
+        # only_self_att=True => context_dim None => attn2 is self-attention too (attention.py:347-348)
+        super().__init__(in_channels, n_heads, d_head, None, use_linear, False, True)
+
+
+class TemporalConvBlock(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        k, pad = (3, 1, 1), (1, 0, 0)
+        self.conv1 = nn.Sequential(nn.GroupNorm(32, channels), nn.SiLU(), nn.Conv3d(channels, channels, k, padding=pad))
+        for name in ("conv2", "conv3", "conv4"):
+            setattr(self, name, nn.Sequential(nn.GroupNorm(32, channels), nn.SiLU(), nn.Dropout(0.1),
+                                              nn.Conv3d(channels, channels, k, padding=pad)))
+        nn.init.zeros_(self.conv4[-1].weight)
+        nn.init.zeros_(self.conv4[-1].bias)
+
+
+class ResBlock(nn.Module):
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_temporal_conv=False):
+        super().__init__()
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.in_layers = nn.Sequential(nn.GroupNorm(32, channels), nn.SiLU(),
+                                       nn.Conv2d(channels, self.out_channels, 3, padding=1))
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, self.out_channels))
+        self.out_layers = nn.Sequential(nn.GroupNorm(32, self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
+                                        nn.Conv2d(self.out_channels, self.out_channels, 3, padding=1))
+        for p in self.out_layers[-1].parameters():
+            nn.init.zeros_(p)
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        else:
+            self.skip_connection = nn.Conv2d(channels, self.out_channels, 1)
+        self.use_temporal_conv = use_temporal_conv
+        if use_temporal_conv:
+            self.temopral_conv = TemporalConvBlock(self.out_channels)  # (sic) reference spelling
+
+
+class Downsample(nn.Module):
+    def __init__(self, channels, out_channels=None):
+        super().__init__()
+        self.op = nn.Conv2d(channels, out_channels or channels, 3, stride=2, padding=1)
+
+
+class Upsample(nn.Module):
+    def __init__(self, channels, out_channels=None):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, out_channels or channels, 3, padding=1)
+
+
+class TimestepEmbedSequential(nn.Sequential):
+    pass
+
+
+# ------------------------------------------------------------------------------------------------
+class _Ctx:
+    """Per-forward execution state."""
+    __slots__ = ("ops", "fp", "F", "H", "W", "emb_bias", "ctx_text", "ctx_img", "w")
+
+
+class UNetModel(nn.Module):
+    def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 dropout=0.0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, context_dim=None,
+                 use_scale_shift_norm=False, resblock_updown=False, num_heads=-1, num_head_channels=-1,
+                 transformer_depth=1, use_linear=False, use_checkpoint=False, temporal_conv=False,
+                 tempspatial_aware=False, temporal_attention=True, use_relative_position=True,
+                 use_causal_attention=False, temporal_length=None, use_fp16=False, addition_attention=False,
+                 temporal_selfatt_only=True, image_cross_attention=False,
+                 image_cross_attention_scale_learnable=False, default_fs=4, fs_condition=False):
+        super().__init__()
+        _unsupported(dims != 2, "dims != 2")
+        _unsupported(use_scale_shift_norm, "use_scale_shift_norm")
+        _unsupported(resblock_updown, "resblock_updown")
+        _unsupported(not conv_resample, "conv_resample=False")
+        _unsupported(transformer_depth != 1, "transformer_depth != 1")
+        _unsupported(tempspatial_aware, "tempspatial_aware")
+        _unsupported(use_relative_position, "use_relative_position")
+        _unsupported(use_causal_attention, "use_causal_attention")
+        _unsupported(image_cross_attention_scale_learnable, "image_cross_attention_scale_learnable")
+        _unsupported(not temporal_selfatt_only, "temporal cross-attention")
+        _unsupported(num_head_channels == -1, "num_heads without num_head_channels")
+        self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
+        self.num_res_blocks, self.attention_resolutions = num_res_blocks, attention_resolutions
+        self.dropout, self.channel_mult, self.conv_resample = dropout, channel_mult, conv_resample
+        self.temporal_attention = temporal_attention
+        self.use_checkpoint = use_checkpoint
+        self.dtype = torch.bfloat16  # as the reference hard-codes (openaimodel3d.py:364)
+        self.addition_attention = addition_attention
+        self.temporal_length = temporal_length
+        self.image_cross_attention = image_cross_attention
+        self.default_fs, self.fs_condition = default_fs, fs_condition
+        ted = model_channels * 4
+
+        self.time_embed = nn.Sequential(nn.Linear(model_channels, ted), nn.SiLU(), nn.Linear(ted, ted))
+        if fs_condition:
+            self.fps_embedding = nn.Sequential(nn.Linear(model_channels, ted), nn.SiLU(), nn.Linear(ted, ted))
+            nn.init.zeros_(self.fps_embedding[-1].weight)
+            nn.init.zeros_(self.fps_embedding[-1].bias)
+        self.input_blocks = nn.ModuleList(
+            [TimestepEmbedSequential(nn.Conv2d(in_channels, model_channels, 3, padding=1))])
+        if addition_attention:
+            self.init_attn = TimestepEmbedSequential(
+                TemporalTransformer(model_channels, 8, num_head_channels, use_linear=False))
+
+        def attn_layers(ch):
+            heads = ch // num_head_channels
+            layers = [SpatialTransformer(ch, heads, num_head_channels, context_dim, use_linear, image_cross_attention)]
+            if temporal_attention:
+                layers.append(TemporalTransformer(ch, heads, num_head_channels, use_linear))
+            return layers
+
+        input_block_chans = [model_channels]
+        ch, ds = model_channels, 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [ResBlock(ch, ted, dropout, mult * model_channels, temporal_conv)]
+                ch = mult * model_channels
+                if ds in attention_resolutions:
+                    layers += attn_layers(ch)
+                self.input_blocks.append(TimestepEmbedSequential(*layers))
+                input_block_chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbedSequential(Downsample(ch, ch)))
+                input_block_chans.append(ch)
+                ds *= 2
+        mid = [ResBlock(ch, ted, dropout, None, temporal_conv)] + attn_layers(ch)[:2 if temporal_attention else 1]
+        mid.append(ResBlock(ch, ted, dropout, None, temporal_conv))
+        self.middle_block = TimestepEmbedSequential(*mid)
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                ich = input_block_chans.pop()
+                layers = [ResBlock(ch + ich, ted, dropout, mult * model_channels, temporal_conv)]
+                ch = model_channels * mult
+                if ds in attention_resolutions:
+                    layers += attn_layers(ch)
+                if level and i == num_res_blocks:
+                    layers.append(Upsample(ch, ch))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+        self.out = nn.Sequential(nn.GroupNorm(32, ch), nn.SiLU(), nn.Conv2d(model_channels, out_channels, 3, padding=1))
+        for p in self.out[-1].parameters():
+            nn.init.zeros_(p)
+
+        self.ops = None
+        self.fp = None
+        self._packed = None
+
+    # ---- kernel-side weights -------------------------------------------------------------------
+    def load_state_dict(self, *a, **k):
+        self._packed = None  # packed copies are stale
+        return super().load_state_dict(*a, **k)
+
+    def bind(self, ops, fp=None):
+        """Select the op table (HipOps in production) and optional frame-parallel context."""
+        self.ops, self.fp = ops, fp
+        self._packed = None
+        return self
+
+    def prepare(self):
+        """Build the packed, device-resident weight set for the bound op table."""
+        ops = self.ops
+        dev, dt = ops.device, ops.dtype
+        W = {}
+        wt = lambda t: t.detach().to(device=dev, dtype=dt).contiguous()
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+        def lin(mod):
+            w = mod.weight
+            if w.dim() > 2:  # 1x1 Conv1d / Conv2d
+                w = w.reshape(w.shape[0], w.shape[1])
+            return wt(w), (None if mod.bias is None else f32(mod.bias))
+
+        emb_w, emb_b, off = [], [], 0
+        for name, mod in self.named_modules():
+            if isinstance(mod, ResBlock):
+                e = {}
+                e["gn1"] = (f32(mod.in_layers[0].weight), f32(mod.in_layers[0].bias))
+                e["conv1"] = wt(packing.pack_conv3x3(mod.in_layers[2].weight))
+                e["gn2"] = (f32(mod.out_layers[0].weight), f32(mod.out_layers[0].bias))
+                e["conv2"] = (wt(packing.pack_conv3x3(mod.out_layers[3].weight)), f32(mod.out_layers[3].bias))
+                e["skip"] = None if isinstance(mod.skip_connection, nn.Identity) else lin(mod.skip_connection)
+                # emb_layers of every ResBlock run as ONE batched GEMV per forward; the conv1 bias is
+                # folded into the same vector: h = conv1(.) + (b_conv1 + W_emb silu(emb) + b_emb)
+                emb_w.append(mod.emb_layers[1].weight)
+                emb_b.append(mod.emb_layers[1].bias.float() + mod.in_layers[2].bias.float())
+                e["emb_slice"] = (off, off + mod.out_channels)
+                off += mod.out_channels
+                if mod.use_temporal_conv:
+                    tc = mod.temopral_conv
+                    e["tconv"] = [((f32(s[0].weight), f32(s[0].bias)), wt(packing.pack_conv_t3(s[-1].weight)),
+                                   f32(s[-1].bias)) for s in (tc.conv1, tc.conv2, tc.conv3, tc.conv4)]
+                W[name] = e
+            elif isinstance(mod, _Transformer):
+                blk = mod.transformer_blocks[0]
+                e = {"norm": (f32(mod.norm.weight), f32(mod.norm.bias)), "proj_in": lin(mod.proj_in),
+                     "proj_out": lin(mod.proj_out)}
+                for i, ln in enumerate((blk.norm1, blk.norm2, blk.norm3), 1):
+                    e[f"ln{i}"] = (f32(ln.weight), f32(ln.bias))
+                a1 = blk.attn1
+                e["a1_qkv"] = wt(torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0))
+                e["a1_out"] = lin(a1.to_out[0])
+                a2 = blk.attn2
+                if a2.self_attn:
+                    e["a2_qkv"] = wt(torch.cat([a2.to_q.weight, a2.to_k.weight, a2.to_v.weight], 0))
+                else:
+                    e["a2_q"] = wt(a2.to_q.weight)
+                    e["a2_kv"] = wt(torch.cat([a2.to_k.weight, a2.to_v.weight], 0))
+                    if a2.image_cross_attention:
+                        e["a2_kv_ip"] = wt(torch.cat([a2.to_k_ip.weight, a2.to_v_ip.weight], 0))
+                e["a2_out"] = lin(a2.to_out[0])
+                gw, gb = packing.pack_geglu(blk.ff.net[0].proj.weight.detach(), blk.ff.net[0].proj.bias.detach())
+                e["ff1"] = (wt(gw), f32(gb))
+                e["ff2"] = lin(blk.ff.net[2])
+                W[name] = e
+            elif isinstance(mod, Downsample):
+                W[name] = (wt(packing.pack_conv3x3(mod.op.weight)), f32(mod.op.bias))
+            elif isinstance(mod, Upsample):
+                W[name] = (wt(packing.pack_conv3x3(mod.conv.weight)), f32(mod.conv.bias))
+        W["emb_all"] = (wt(torch.cat(emb_w, 0)), f32(torch.cat(emb_b, 0)))
+        W["stem"] = (wt(packing.pack_conv3x3(self.input_blocks[0][0].weight)), f32(self.input_blocks[0][0].bias))
+        W["out_gn"] = (f32(self.out[0].weight), f32(self.out[0].bias))
+        W["out_conv"] = (wt(packing.pack_conv3x3(self.out[2].weight)), f32(self.out[2].bias))
+        W["time_embed"] = [lin(self.time_embed[0]), lin(self.time_embed[2])]
+        if self.fs_condition:
+            W["fps_embedding"] = [lin(self.fps_embedding[0]), lin(self.fps_embedding[2])]
+        self._names = {m: n for n, m in self.named_modules()}
+        self._packed = W
+        return self
+
+    # ---- graph ---------------------------------------------------------------------------------
+    def _gn(self, c, x, gb, eps, silu, per_frame):
+        ops = c.ops
+        if per_frame:
+            return ops.groupnorm(x, gb[0], gb[1], eps, c.F, silu)
+        red = c.fp.reduce_stats if c.fp is not None else None
+        return ops.groupnorm(x, gb[0], gb[1], eps, 1, silu, stats_reduce=red)
+
+    def _res_block(self, c, mod, x):
+        ops, e = c.ops, c.w[self._names[mod]]
+        P = c.H * c.W
+        h = self._gn(c, x, e["gn1"], 1e-5, True, True)
+        lo, hi = e["emb_slice"]
+        h = ops.conv3x3(h, e["conv1"], c.emb_bias[lo:hi], c.F, c.H, c.W)
+        h = self._gn(c, h, e["gn2"], 1e-5, True, True)
+        skip = x if e["skip"] is None else ops.gemm(x, e["skip"][0], e["skip"][1])
+        h = ops.conv3x3(h, e["conv2"][0], e["conv2"][1], c.F, c.H, c.W, residual=skip)
+        if mod.use_temporal_conv:
+            ident = h
+            for i, (gb, wp, b) in enumerate(e["tconv"]):
+                t = self._gn(c, h, gb, 1e-5, True, False)
+                lo_h = hi_h = None
+                if c.fp is not None:
+                    lo_h, hi_h = c.fp.exchange_halo(t, P)
+                h = ops.conv_t3(t, wp, b, c.F, P, residual=ident if i == 3 else None, halo_lo=lo_h, halo_hi=hi_h)
+        return h
+
+    def _block(self, c, e, h, mod, temporal):
+        """BasicTransformerBlock on tokens h [F*P, inner] (attention.py:242-246)."""
+        ops = c.ops
+        P = c.H * c.W
+        inner, heads = mod.inner, mod.heads
+        v3 = lambda t, n: t.view(c.F, P, n)
+        for which in (1, 2):
+            y = ops.layernorm(h, *e[f"ln{which}"])
+            key = f"a{which}_qkv"
+            if key in e:  # self-attention, fused q|k|v projection
+                qkv = v3(ops.gemm(y, e[key]), 3 * inner)
+                q, k, v = qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:]
+                if temporal:
+                    if c.fp is not None:
+                        k, v = c.fp.gather_kv(qkv, inner, P)
+                    a = ops.attention_temporal(q, k, v, heads)
+                else:
+                    a = ops.attention(q, k, v, heads)
+            else:  # spatial cross-attention: text keys shared by all frames + per-frame image keys
+                q = v3(ops.gemm(y, e["a2_q"]), inner)
+                kv_t = ops.gemm(c.ctx_text, e["a2_kv"]).view(1, -1, 2 * inner)
+                k2 = v2 = None
+                if "a2_kv_ip" in e:
+                    kv_i = ops.gemm(c.ctx_img, e["a2_kv_ip"]).view(c.F, -1, 2 * inner)
+                    k2, v2 = kv_i[..., :inner], kv_i[..., inner:]
+                a = ops.attention(q, kv_t[..., :inner], kv_t[..., inner:], heads, k2, v2, 1.0)
+            h = ops.gemm(a.view(c.F * P, inner), *e[f"a{which}_out"], residual=h)
+        y = ops.layernorm(h, *e["ln3"])
+        g = ops.gemm(y, e["ff1"][0], e["ff1"][1], act="geglu")
+        return ops.gemm(g, e["ff2"][0], e["ff2"][1], residual=h)
+
+    def _transformer(self, c, mod, x, temporal):
+        ops, e = c.ops, c.w[self._names[mod]]
+        h = self._gn(c, x, e["norm"], 1e-6, False, not temporal)
+        h = ops.gemm(h, *e["proj_in"])
+        h = self._block(c, e, h, mod, temporal)
+        return ops.gemm(h, *e["proj_out"], residual=x)
+
+    def _run(self, c, seq, h):
+        for layer in seq:
+            if isinstance(layer, ResBlock):
+                h = self._res_block(c, layer, h)
+            elif isinstance(layer, SpatialTransformer):
+                h = self._transformer(c, layer, h, False)
+            elif isinstance(layer, TemporalTransformer):
+                h = self._transformer(c, layer, h, True)
+            elif isinstance(layer, Downsample):
+                wp, b = c.w[self._names[layer]]
+                h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W, stride=2)
+                c.H, c.W = (c.H + 1) // 2, (c.W + 1) // 2
+            elif isinstance(layer, Upsample):
+                wp, b = c.w[self._names[layer]]
+                h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W, upsample=True)
+                c.H, c.W = 2 * c.H, 2 * c.W
+            elif isinstance(layer, nn.Conv2d):  # stem
+                wp, b = c.w["stem"]
+                h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W)
+            else:
+                raise TypeError(type(layer))
+        return h
+
+    def _embed(self, c, timesteps, fs):
+        ops, W = c.ops, c.w
+        mlp = lambda p, v: ops.gemv(p[1][0], ops.gemv(p[0][0], v, p[0][1], act="silu"), p[1][1])
+        dev = ops.device
+        emb = mlp(W["time_embed"], timestep_embedding(timesteps.to(dev), self.model_channels)[0].contiguous())
+        if self.fs_condition:
+            if fs is None:
+                fs = torch.tensor([self.default_fs], dtype=torch.long, device=dev)
+            emb = emb + mlp(W["fps_embedding"], timestep_embedding(fs.to(dev), self.model_channels)[0].contiguous())
+        # every ResBlock's  b_conv1 + b_emb + W_emb . silu(emb)  in one launch
+        return ops.gemv(W["emb_all"][0], emb, W["emb_all"][1], silu_in=True)
+
+    @torch.no_grad()
+    def forward(self, x, timesteps, context=None, features_adapter=None, fs=None, **kwargs):
+        """x (1, C_in, t_local, h, w), timesteps (1,), context (1, 77 + 16*T, 1024), fs (1,) ->
+        (1, C_out, t_local, h, w) in the op table's dtype.  In frame-sharded mode x holds this rank's
+        frames and `context` is the full-clip context (image tokens are sliced by `fp`)."""
+        if self.ops is None:
+            raise RuntimeError("UNetModel.bind(ops) must be called before forward (no implicit CPU fallback)")
+        _unsupported(features_adapter is not None, "features_adapter")
+        if self._packed is None:
+            self.prepare()
+        b, cin, t, hh, ww = x.shape
+        assert b == 1, "the reference path runs batch size 1 (model.py:794)"
+        c = _Ctx()
+        c.ops, c.fp, c.w = self.ops, self.fp, self._packed
+        c.F, c.H, c.W = t, hh, ww
+        ops = c.ops
+        T_total = t if c.fp is None else c.fp.total_frames
+        ctx = context[0].to(device=ops.device, dtype=ops.dtype)
+        if ctx.shape[0] == 77 + T_total * 16:  # per-frame image conditioning (openaimodel3d.py:559-564)
+            c.ctx_text = ctx[:77].contiguous()
+            img = ctx[77:].reshape(T_total, 16, -1)
+            if c.fp is not None:
+                img = img[c.fp.frame_offset:c.fp.frame_offset + t]
+            c.ctx_img = img.reshape(t * 16, -1).contiguous()
+        else:
+            raise NotImplementedError("context without per-frame image tokens")
+        c.emb_bias = self._embed(c, timesteps, fs)
+
+        if x.dtype == torch.float32:
+            h = ops.pack_input(x[0].reshape(cin, t, hh * ww).contiguous(), None)
+        else:
+            h = x[0].reshape(cin, t, hh * ww).permute(1, 2, 0).reshape(t * hh * ww, cin).to(ops.dtype).contiguous()
+        hs = []
+        for i, module in enumerate(self.input_blocks):
+            h = self._run(c, module, h)
+            if i == 0 and self.addition_attention:
+                h = self._run(c, self.init_attn, h)
+            hs.append((h, c.H, c.W))
+        h = self._run(c, self.middle_block, h)
+        for module in self.output_blocks:
+            skip, sh, sw = hs.pop()
+            assert (sh, sw) == (c.H, c.W)
+            h = torch.cat([h, skip], dim=1)
+            h = self._run(c, module, h)
+        h = self._gn(c, h, c.w["out_gn"], 1e-5, True, True)
+        y = ops.conv3x3(h, c.w["out_conv"][0], c.w["out_conv"][1], c.F, c.H, c.W)
+        return ops.unpack_output(y, t, hh * ww).reshape(1, self.out_channels, t, hh, ww)

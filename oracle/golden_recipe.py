@@ -1,0 +1,37 @@
+"""Seeds and synthetic-input recipes shared by oracle/make_golden.py (which runs the real reference)
+and the tests that replay the same inputs through the oracle / the product.  Test infrastructure."""
+import numpy as np
+
+from open_pandora_amd import synth
+
+WEIGHT_SEED, INPUT_SEED, NOISE_SEED = 20230211, 123, 7
+
+UNET_SMALL_CASES = (("mc64_8x8_t500", 64, 8, 8, 500, 15), ("mc64_8x16_t999", 64, 8, 16, 999, 24),
+                    ("mc128_8x8_t37", 128, 8, 8, 37, 3))
+DDIM_SMALL_CASES = ((5, 0.0, 4.0), (10, 0.0, 4.0), (20, 1.0, 4.0), (10, 0.0, 1.0), (10, 1.0, 4.0))
+
+
+def module_input(name, *shape):
+    return (synth.uniform_pm1(int(np.prod(shape)), INPUT_SEED, name) * 3 ** 0.5).reshape(*shape)
+
+
+def module_inputs():
+    return {"x4": module_input("mod/x4", 16, 64, 4, 6), "x5": module_input("mod/x5", 1, 64, 16, 4, 6),
+            "tok": module_input("mod/tok", 16, 24, 128), "ctx": module_input("mod/ctx", 16, 77 + 16, 1024),
+            "emb": module_input("mod/emb", 16, 256)}
+
+
+def sampler_inputs(h, w, T=16):
+    ins = synth.synth_inputs(h, w, T, seed=INPUT_SEED)
+    cond = {"c_crossattn": [ins["c_crossattn"]], "c_concat": [ins["c_concat"]]}
+    uc = {"c_crossattn": [ins["uc_crossattn"]], "c_concat": [ins["c_concat"]]}
+    return ins, cond, uc
+
+
+def noises(shape, S):
+    return [synth.synth_noise(shape, NOISE_SEED, i) for i in range(S)]
+
+
+def digest_of(t, stride, n):
+    flat = t.detach().float().reshape(-1)
+    return flat[::int(stride)][:n]

