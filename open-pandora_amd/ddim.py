@@ -56,11 +56,15 @@ class DDIMSampler:
         ac32 = m.alphas_cumprod.detach().to(torch.float32).cpu()  # bf16-quantised values, as f32
         assert ac32.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
         idx = torch.as_tensor(np.ascontiguousarray(ts), dtype=torch.long)
-        a = ac32[idx].to(torch.float64)
+        a32 = ac32[idx]
+        a = a32.to(torch.float64)
         a_prev = torch.cat([ac32[0:1], ac32[idx[:-1]]]).to(torch.float64)
-        # reference: float64 array/tensor arithmetic, then cast to the latent dtype per step
-        sig = ddim_eta * torch.sqrt((1 - a_prev) / (1 - a) * (1 - a / a_prev))
-        self.ddim_alphas = a.to(torch.float32)
+        # reference arithmetic (utils_diffusion.py:86): `alphas` is an f32 tensor and `alphas_prev` a
+        # float64 ndarray, so `(1 - alphas_prev) / (1 - alphas)` runs as ndarray.__truediv__ ->
+        # Tensor.__rtruediv__ = f32 reciprocal(1 - alphas) * float64 array; the rest is float64.
+        sig = (1 - a32).reciprocal().to(torch.float64) * (1 - a_prev) * (1 - a / a_prev)
+        sig = torch.from_numpy(ddim_eta * np.sqrt(sig.numpy()))  # np.sqrt as in the reference
+        self.ddim_alphas = a32
         self.ddim_alphas_prev = a_prev.numpy()
         self.ddim_sigmas = sig
         self.ddim_sqrt_one_minus_alphas = torch.sqrt(1.0 - self.ddim_alphas)
