@@ -36,6 +36,12 @@ extern "C" {
 
 #define PM_F16 1
 #define PM_BF16 2
+#define PM_F32 3 /* only where an entry point says so (norm inputs, model outputs, the residual stream) */
+
+/* GEMM-family flags.  The U-Net's residual stream (the tensor every block adds into) is kept in f32
+ * so that 16-bit rounding happens once per branch operand instead of once per residual add. */
+#define PM_FLAG_A_F32 1   /* the A operand (activations) is f32; rounded to `dtype` while staging   */
+#define PM_FLAG_OUT_F32 2 /* C and `residual` are f32 (bias/act/residual add and the store in f32) */
 
 /* activation fused into a GEMM / conv epilogue */
 #define PM_ACT_NONE 0
@@ -51,13 +57,14 @@ int pm_abi_version(void);
  * :269,290,302,306 (proj_in/out), :336,362,374,405, :418-442 (GEGLU feed-forward),
  * openaimodel3d.py:185-190 (1x1 skip_connection).
  *   epilogue: + bias[n] (f32, may be NULL) -> act -> + residual[m, n] (may be NULL) -> store.
+ *   flags: PM_FLAG_A_F32 (lda % 4 == 0), PM_FLAG_OUT_F32 (not with GEGLU).
  *   PM_ACT_GEGLU: W holds 2*Nout rows interleaved [16 value rows | 16 gate rows] per 32-row group,
  *     bias likewise; C is [M, Nout] with Nout = N/2:  C = (v + bv) * gelu_erf(g + bg).
  *   requirements: K % 64 == 0, lda/ldw % 8 == 0, 16-byte aligned bases; any M, N >= 1.
  */
 int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
             const void* residual, int64_t ldr, void* C, int64_t ldc, int64_t M, int64_t N,
-            int64_t K, int act, int dtype, void* stream);
+            int64_t K, int act, int flags, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * pm_conv2d_3x3: implicit-GEMM 3x3 convolution, padding 1, on channels-last frames.
@@ -72,7 +79,7 @@ int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float*
 int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const float* bias,
                   const void* residual, int64_t ldr, void* y, int64_t ldy, int64_t F, int64_t H,
                   int64_t W, int64_t Cin, int64_t Cout, int stride, int upsample2x,
-                  const void* zero_page, int dtype, void* stream);
+                  const void* zero_page, int flags, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * pm_conv_temporal_k3: Conv3d kernel (3,1,1), padding (1,0,0) = 3-tap conv along the frame axis.
@@ -85,14 +92,14 @@ int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const float* bias,
 int pm_conv_temporal_k3(const void* x, int64_t ldx, const void* halo_lo, const void* halo_hi,
                         const void* Wp, const float* bias, const void* residual, int64_t ldr,
                         void* y, int64_t ldy, int64_t F, int64_t P, int64_t Cin, int64_t Cout,
-                        const void* zero_page, int dtype, void* stream);
+                        const void* zero_page, int flags, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm(32 groups) on channels-last data, optional fused SiLU.
  * replaces GroupNormSpecific / nn.GroupNorm call sites: per-frame statistics (openaimodel3d.py:154-158,
  * 178-183,546-550; attention.py:265,297) and (T,H,W) statistics (openaimodel3d.py:258-269;
  * attention.py:331,368).
- *   x: [NI, P, C]: NI independent instances (NI = frames for per-frame statistics, NI = 1 with
+ *   x: [NI, P, C] of in_dtype (PM_F16 / PM_BF16 / PM_F32): NI independent instances (NI = frames for per-frame statistics, NI = 1 with
  *   P = F*H*W for (T,H,W) statistics); C % 8 == 0, (C/8) <= 1024, C % groups == 0.
  *   pm_groupnorm_stats writes partial {sum, sum of squares} per (instance, chunk, group) into
  *   `partials` [NI, nchunks, groups, 2] f32; nchunks = pm_groupnorm_nchunks(P, C).
@@ -102,18 +109,20 @@ int pm_conv_temporal_k3(const void* x, int64_t ldx, const void* halo_lo, const v
  */
 int64_t pm_groupnorm_nchunks(int64_t P, int64_t C);
 int pm_groupnorm_stats(const void* x, int64_t ldx, float* partials, int64_t NI, int64_t P,
-                       int64_t C, int groups, int dtype, void* stream);
+                       int64_t C, int groups, int in_dtype, void* stream);
 int pm_groupnorm_apply(const void* x, int64_t ldx, const float* partials, int64_t nchunks,
                        const float* gamma, const float* beta, void* y, int64_t ldy, int64_t NI,
                        int64_t P, int64_t C, int groups, double count, float eps, int silu,
-                       int dtype, void* stream);
+                       int in_dtype, int out_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * pm_layernorm: LayerNorm over the last dimension; replaces BasicTransformerBlock.norm1/2/3
- * (attention.py:225-227,243-245).  x, y: [M, C]; gamma, beta f32 [C]; C % 8 == 0, C <= 4096.
+ * (attention.py:225-227,243-245).  x [M, C] of in_dtype (16-bit or PM_F32), y [M, C] of out_dtype
+ * (16-bit); gamma, beta f32 [C]; C % 8 == 0, C <= 4096.
  */
 int pm_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y,
-                 int64_t ldy, int64_t M, int64_t C, float eps, int dtype, void* stream);
+                 int64_t ldy, int64_t M, int64_t C, float eps, int in_dtype, int out_dtype,
+                 void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * pm_attention: softmax(q k^T * scale) v with head dim 64, flash-style (no score matrix in HBM),
@@ -161,7 +170,8 @@ int pm_gemv_f32(const void* W, int64_t ldw, const float* x, const float* bias, f
  *   v = e_u + cfg * (e_c - e_u)   (e_u may be NULL: v = e_c)
  *   eps = sqrt_ac * v + sqrt_1mac * x ;  x0 = (sqrt_ac * x - sqrt_1mac * v) * rescale
  *   x_prev = sqrt_a_prev * x0 + dir_coef * eps + sigma * noise   (noise may be NULL when sigma == 0)
- *   e_c / e_u are model outputs in `dtype`; x, noise, x_prev, pred_x0 are f32; n = element count.
+ *   e_c / e_u are model outputs in `dtype` (PM_F16 / PM_BF16 / PM_F32); x, noise, x_prev, pred_x0 are
+ *   f32; n = element count.
  */
 int pm_ddim_update(const float* x, const void* e_c, const void* e_u, const float* noise,
                    float* x_prev, float* pred_x0, int64_t n, float cfg, float sqrt_ac,
@@ -172,7 +182,7 @@ int pm_ddim_update(const float* x, const void* e_c, const void* e_u, const float
  * layout helpers on the path boundary (DiffusionWrapper 'hybrid' concat ddpm3d.py:1077-1081 and the
  * `b c t h w -> (b t) c h w` shuffles openaimodel3d.py:570,606):
  *   pm_pack_input:  x f32 [C1, F, P] and cond f32 [C2, F, P]  ->  y dtype [F, P, C1 + C2]
- *   pm_unpack_output: y dtype [F, P, C] -> out (dtype, same as the model) [C, F, P]
+ *   pm_unpack_output: y [F, P, C] -> out [C, F, P], both of `dtype` (PM_F16 / PM_BF16 / PM_F32)
  */
 int pm_pack_input(const float* x, const float* cond, void* y, int64_t C1, int64_t C2, int64_t F,
                   int64_t P, int dtype, void* stream);

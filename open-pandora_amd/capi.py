@@ -9,7 +9,8 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpandora_mi355x.so")
 
-PM_F16, PM_BF16 = 1, 2
+PM_F16, PM_BF16, PM_F32 = 1, 2, 3
+PM_FLAG_A_F32, PM_FLAG_OUT_F32 = 1, 2
 PM_ACT_NONE, PM_ACT_SILU, PM_ACT_GEGLU = 0, 1, 2
 ACT_CODES = {"none": PM_ACT_NONE, None: PM_ACT_NONE, "silu": PM_ACT_SILU, "geglu": PM_ACT_GEGLU}
 
@@ -18,21 +19,21 @@ SIGNATURES = {
     "pm_strerror": (c_char_p, [c_int]),
     "pm_abi_version": (c_int, []),
     "pm_gemm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
-                        c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
+                        c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
     "pm_conv2d_3x3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                               c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
-                              c_void_p, c_int, c_void_p]),
+                              c_void_p, c_int, c_int, c_void_p]),
     "pm_conv_temporal_k3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64,
-                                    c_int64, c_void_p, c_int, c_void_p]),
+                                    c_int64, c_void_p, c_int, c_int, c_void_p]),
     "pm_groupnorm_nchunks": (c_int64, [c_int64, c_int64]),
     "pm_groupnorm_stats": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int,
                                    c_int, c_void_p]),
     "pm_groupnorm_apply": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_double,
-                                   c_float, c_int, c_int, c_void_p]),
+                                   c_float, c_int, c_int, c_int, c_void_p]),
     "pm_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
-                             c_int64, c_float, c_int, c_void_p]),
+                             c_int64, c_float, c_int, c_int, c_void_p]),
     "pm_attention": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64,
                              c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float,
                              c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int,

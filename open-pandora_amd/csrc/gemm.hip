@@ -8,6 +8,7 @@
 // barrier per K-tile, two LDS buffers); LDS rows are 128 B with the 16-byte chunk index XOR-ed by
 // (row & 7) so the ds_read_b128 fragment reads spread over the banks.  The epilogue goes through LDS
 // (f32) so that residual loads and output stores are full 16-byte row segments.
+#include <type_traits>
 #include "common.hpp"
 
 namespace pm {
@@ -26,6 +27,7 @@ struct GemmParams {
   int64_t ldc;
   int M, N, K;
   int act;
+  int out32;
   int ntiles;
   // conv3x3
   int Hin, Win, Hv, Wv, Cin, Ho, Wo, stride, ups;
@@ -48,8 +50,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
-template <typename T, int AMODE>
+template <typename T, int AMODE, bool A32>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+  typedef typename std::conditional<A32, float, T>::type TA;  // storage type of the A operand
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const As = smem;                    // [2][TILE_BYTES]
   char* const Bs = smem + 2 * TILE_BYTES;   // [2][TILE_BYTES]
@@ -64,14 +67,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   const int mt = wg / p.ntiles, nt = wg - mt * p.ntiles;
   const int m0 = mt * BM, n0 = nt * BN;
 
-  const T* __restrict__ Ag = reinterpret_cast<const T*>(p.A);
+  const TA* __restrict__ Ag = reinterpret_cast<const TA*>(p.A);
   const T* __restrict__ Wg = reinterpret_cast<const T*>(p.Wt);
-  const T* zero = reinterpret_cast<const T*>(p.zero);
+  const TA* zero = reinterpret_cast<const TA*>(p.zero);
+  const T* zero_w = reinterpret_cast<const T*>(p.zero);
 
   // ---- loader state: this thread stages chunk `lc` (8 elements) of rows lr + 32*j ----
   const int lc = tid & 7;
   const int lr = tid >> 3;
-  const T* a_base[4];
+  const TA* a_base[4];
   const T* b_base[4];
   int a_y[4], a_x[4];  // conv3x3: iy0, ix0 ; convt3: frame, unused
 #pragma unroll
@@ -107,13 +111,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     ch -= tap * p.Cin;
   }
 
-  u32x4 ra[4], rb[4];
+  u32x4 ra[4], ra_hi[4], rb[4];  // ra_hi: second half of an f32 A chunk (A32 only)
   auto load_tile = [&](int kt) {
     const int k = kt * BK + lc * 8;
     const bool kin = k < p.K;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const T* src;
+      const TA* src;
       if (AMODE == A_DENSE) {
         src = kin ? a_base[j] + k : zero;
       } else if (AMODE == A_CONV3X3) {
@@ -130,17 +134,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         if (!kin) {
           src = zero;
         } else if (sf < 0) {
-          src = p.halo_lo ? reinterpret_cast<const T*>(p.halo_lo) + (int64_t)a_x[j] * p.lda + ch
+          src = p.halo_lo ? reinterpret_cast<const TA*>(p.halo_lo) + (int64_t)a_x[j] * p.lda + ch
                           : zero;
         } else if (sf >= p.F) {
-          src = p.halo_hi ? reinterpret_cast<const T*>(p.halo_hi) + (int64_t)a_x[j] * p.lda + ch
+          src = p.halo_hi ? reinterpret_cast<const TA*>(p.halo_hi) + (int64_t)a_x[j] * p.lda + ch
                           : zero;
         } else {
           src = a_base[j] + (int64_t)sf * p.P * p.lda + ch;
         }
       }
       ra[j] = ld_global16(src);
-      rb[j] = ld_global16(kin ? b_base[j] + k : zero);
+      if (A32) ra_hi[j] = ld_global16(src + 4);
+      rb[j] = ld_global16(kin ? b_base[j] + k : zero_w);
     }
     if (AMODE != A_DENSE) {  // advance to the next K-tile
       ch += BK;
@@ -155,7 +160,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     for (int j = 0; j < 4; ++j) {
       const int row = lr + 32 * j;
       const int off = row * 128 + ((lc ^ (row & 7)) << 4);
-      *reinterpret_cast<u32x4*>(As + buf * TILE_BYTES + off) = ra[j];
+      if (A32) {  // f32 residual-stream operand: round to the MFMA input type while staging
+        union { u32x4 u; float f[4]; } lo, hi;
+        lo.u = ra[j];
+        hi.u = ra_hi[j];
+        Pack8<T> cv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          cv.e[e] = from_f32<T>(lo.f[e]);
+          cv.e[e + 4] = from_f32<T>(hi.f[e]);
+        }
+        *reinterpret_cast<u32x4*>(As + buf * TILE_BYTES + off) = cv.u;
+      } else {
+        *reinterpret_cast<u32x4*>(As + buf * TILE_BYTES + off) = ra[j];
+      }
       *reinterpret_cast<u32x4*>(Bs + buf * TILE_BYTES + off) = rb[j];
     }
   };
@@ -235,6 +253,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   float* stage = reinterpret_cast<float*>(smem);  // [64][STAGE_LD]
   T* __restrict__ Cg = reinterpret_cast<T*>(p.C);
   const T* __restrict__ Rg = reinterpret_cast<const T*>(p.R);
+  float* __restrict__ Cf = reinterpret_cast<float*>(p.C);          // PM_FLAG_OUT_F32: residual stream
+  const float* __restrict__ Rf = reinterpret_cast<const float*>(p.R);
+  const bool out32 = p.out32 != 0;
   const int cpr = tw >> 3;         // 8-column chunks per row
   const int rpp = 256 / cpr;       // rows per pass
   const int scol = tid % cpr, srow = tid / cpr;
@@ -258,26 +279,51 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(stage + row * STAGE_LD + scol * 8);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(stage + row * STAGE_LD + scol * 8 + 4);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        T* cptr = Cg + (int64_t)m * p.ldc + n;
-        const bool full = (n + 8 <= nout) && ((p.ldc & 7) == 0);
-        if (Rg != nullptr) {
-          const T* rptr = Rg + (int64_t)m * p.ldr + n;
-          if (full && ((p.ldr & 7) == 0)) {
-            Pack8<T> rv;
-            rv.u = ld_global16(rptr);
+        if (out32) {
+          float* cptr = Cf + (int64_t)m * p.ldc + n;
+          const bool full = (n + 8 <= nout) && ((p.ldc & 3) == 0);
+          if (Rf != nullptr) {
+            const float* rptr = Rf + (int64_t)m * p.ldr + n;
+            if (full && ((p.ldr & 3) == 0)) {
+              const f32x4 r0 = *reinterpret_cast<const f32x4*>(rptr);
+              const f32x4 r1 = *reinterpret_cast<const f32x4*>(rptr + 4);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += to_f32(rv.e[e]);
-          } else {
-            for (int e = 0; e < 8 && n + e < nout; ++e) v[e] += to_f32(rptr[e]);
+              for (int e = 0; e < 4; ++e) {
+                v[e] += r0[e];
+                v[e + 4] += r1[e];
+              }
+            } else {
+              for (int e = 0; e < 8 && n + e < nout; ++e) v[e] += rptr[e];
+            }
           }
-        }
-        if (full) {
-          Pack8<T> ov;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) ov.e[e] = from_f32<T>(v[e]);
-          st_global16(cptr, ov.u);
+          if (full) {
+            *reinterpret_cast<f32x4*>(cptr) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(cptr + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          } else {
+            for (int e = 0; e < 8 && n + e < nout; ++e) cptr[e] = v[e];
+          }
         } else {
-          for (int e = 0; e < 8 && n + e < nout; ++e) cptr[e] = from_f32<T>(v[e]);
+          T* cptr = Cg + (int64_t)m * p.ldc + n;
+          const bool full = (n + 8 <= nout) && ((p.ldc & 7) == 0);
+          if (Rg != nullptr) {
+            const T* rptr = Rg + (int64_t)m * p.ldr + n;
+            if (full && ((p.ldr & 7) == 0)) {
+              Pack8<T> rv;
+              rv.u = ld_global16(rptr);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += to_f32(rv.e[e]);
+            } else {
+              for (int e = 0; e < 8 && n + e < nout; ++e) v[e] += to_f32(rptr[e]);
+            }
+          }
+          if (full) {
+            Pack8<T> ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov.e[e] = from_f32<T>(v[e]);
+            st_global16(cptr, ov.u);
+          } else {
+            for (int e = 0; e < 8 && n + e < nout; ++e) cptr[e] = from_f32<T>(v[e]);
+          }
         }
       }
     }
@@ -285,17 +331,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   }
 }
 
-template <typename T, int AMODE> static int launch(const GemmParams& p, hipStream_t stream) {
+template <typename T, int AMODE, bool A32> static int launch1(const GemmParams& p, hipStream_t stream) {
   const int mtiles = (p.M + BM - 1) / BM;
   const int grid = mtiles * p.ntiles;
   static bool attr_set = false;  // idempotent; a benign race sets the same value twice
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, AMODE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, AMODE, A32>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<T, AMODE>), dim3(grid), dim3(256), 4 * TILE_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm_kernel<T, AMODE, A32>), dim3(grid), dim3(256), 4 * TILE_BYTES, stream, p);
   return check_launch();
+}
+
+template <typename T, int AMODE> static int launch(const GemmParams& p, int flags, hipStream_t stream) {
+  return (flags & PM_FLAG_A_F32) ? launch1<T, AMODE, true>(p, stream) : launch1<T, AMODE, false>(p, stream);
 }
 
 static int check_common(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K,
@@ -314,29 +364,31 @@ using namespace pm;
 
 extern "C" int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                        const void* residual, int64_t ldr, void* C, int64_t ldc, int64_t M,
-                       int64_t N, int64_t K, int act, int dtype, void* stream) {
+                       int64_t N, int64_t K, int act, int flags, int dtype, void* stream) {
   int rc = check_common(A, W, C, M, N, K, act);
   if (rc) return rc;
-  if ((lda & 7) || (ldw & 7) || lda < K || ldw < K) return PM_E_SHAPE;
+  if ((lda & ((flags & PM_FLAG_A_F32) ? 3 : 7)) || (ldw & 7) || lda < K || ldw < K) return PM_E_SHAPE;
+  if ((flags & PM_FLAG_OUT_F32) && act == PM_ACT_GEGLU) return PM_E_SHAPE;
   GemmParams p{};
   p.A = A; p.lda = lda; p.Wt = W; p.ldw = ldw; p.bias = bias; p.R = residual; p.ldr = ldr;
   p.C = C; p.ldc = ldc; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
+  p.out32 = (flags & PM_FLAG_OUT_F32) ? 1 : 0;
   p.ntiles = (int)((N + BN - 1) / BN);
   p.zero = A;  // dense K tails never occur (K % 8 == 0 and whole chunks only); see kin below
   // A dense K tail (K % 64 != 0) reads chunk-wise: chunks with k >= K take `zero`; any 16 readable
   // bytes would poison the accumulator, so require a real zero source only when a tail exists.
   if (K % BK) return PM_E_SHAPE;  // all Linear layers on the path have K % 64 == 0
-  PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_DENSE>(p, (hipStream_t)stream)));
+  PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_DENSE>(p, flags, (hipStream_t)stream)));
 }
 
 extern "C" int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const float* bias,
                              const void* residual, int64_t ldr, void* y, int64_t ldy, int64_t F,
                              int64_t H, int64_t W, int64_t Cin, int64_t Cout, int stride,
-                             int upsample2x, const void* zero_page, int dtype, void* stream) {
+                             int upsample2x, const void* zero_page, int flags, int dtype, void* stream) {
   if (!zero_page) return PM_E_NULL;
   if (stride != 1 && stride != 2) return PM_E_SHAPE;
   if (upsample2x && stride != 1) return PM_E_SHAPE;
-  if ((Cin & 7) || (ldx & 7) || ldx < Cin) return PM_E_SHAPE;
+  if ((Cin & 7) || (ldx & ((flags & PM_FLAG_A_F32) ? 3 : 7)) || ldx < Cin) return PM_E_SHAPE;
   const int64_t Hv = upsample2x ? 2 * H : H, Wv = upsample2x ? 2 * W : W;
   const int64_t Ho = (Hv + stride - 1) / stride, Wo = (Wv + stride - 1) / stride;
   const int64_t M = F * Ho * Wo, K = 9 * Cin;
@@ -345,28 +397,30 @@ extern "C" int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const f
   GemmParams p{};
   p.A = x; p.lda = ldx; p.Wt = Wp; p.ldw = K; p.bias = bias; p.R = residual; p.ldr = ldr;
   p.C = y; p.ldc = ldy; p.M = (int)M; p.N = (int)Cout; p.K = (int)K; p.act = PM_ACT_NONE;
+  p.out32 = (flags & PM_FLAG_OUT_F32) ? 1 : 0;
   p.ntiles = (int)((Cout + BN - 1) / BN);
   p.Hin = (int)H; p.Win = (int)W; p.Hv = (int)Hv; p.Wv = (int)Wv; p.Cin = (int)Cin;
   p.Ho = (int)Ho; p.Wo = (int)Wo; p.stride = stride; p.ups = upsample2x ? 1 : 0;
   p.zero = zero_page;
-  PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_CONV3X3>(p, (hipStream_t)stream)));
+  PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_CONV3X3>(p, flags, (hipStream_t)stream)));
 }
 
 extern "C" int pm_conv_temporal_k3(const void* x, int64_t ldx, const void* halo_lo,
                                    const void* halo_hi, const void* Wp, const float* bias,
                                    const void* residual, int64_t ldr, void* y, int64_t ldy,
                                    int64_t F, int64_t P, int64_t Cin, int64_t Cout,
-                                   const void* zero_page, int dtype, void* stream) {
+                                   const void* zero_page, int flags, int dtype, void* stream) {
   if (!zero_page) return PM_E_NULL;
-  if ((Cin & 7) || (ldx & 7) || ldx < Cin) return PM_E_SHAPE;
+  if ((Cin & 7) || (ldx & ((flags & PM_FLAG_A_F32) ? 3 : 7)) || ldx < Cin) return PM_E_SHAPE;
   const int64_t M = F * P, K = 3 * Cin;
   int rc = check_common(x, Wp, y, M, Cout, K, PM_ACT_NONE);
   if (rc) return rc;
   GemmParams p{};
   p.A = x; p.lda = ldx; p.Wt = Wp; p.ldw = K; p.bias = bias; p.R = residual; p.ldr = ldr;
   p.C = y; p.ldc = ldy; p.M = (int)M; p.N = (int)Cout; p.K = (int)K; p.act = PM_ACT_NONE;
+  p.out32 = (flags & PM_FLAG_OUT_F32) ? 1 : 0;
   p.ntiles = (int)((Cout + BN - 1) / BN);
   p.Cin = (int)Cin; p.F = (int)F; p.P = (int)P; p.halo_lo = halo_lo; p.halo_hi = halo_hi;
   p.zero = zero_page;
-  PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_CONVT3>(p, (hipStream_t)stream)));
+  PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_CONVT3>(p, flags, (hipStream_t)stream)));
 }

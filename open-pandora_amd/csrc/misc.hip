@@ -125,6 +125,12 @@ extern "C" int pm_ddim_update(const float* x, const void* e_c, const void* e_u, 
   if (sigma != 0.f && !noise) return PM_E_NULL;
   int64_t nb = (n + 255) / 256;
   if (nb > 2048) nb = 2048;
+  if (dtype == PM_F32) {
+    hipLaunchKernelGGL((ddim_kernel<float>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x,
+                       (const float*)e_c, (const float*)e_u, noise, x_prev, pred_x0, n, cfg, sqrt_ac,
+                       sqrt_1mac, rescale, sqrt_a_prev, dir_coef, sigma);
+    return check_launch();
+  }
   PM_DISPATCH_DTYPE(dtype, T,
                     hipLaunchKernelGGL((ddim_kernel<T>), dim3((unsigned)nb), dim3(256), 0,
                                        (hipStream_t)stream, x, (const T*)e_c, (const T*)e_u, noise,
@@ -153,6 +159,11 @@ extern "C" int pm_unpack_output(const void* y, void* out, int64_t C, int64_t F, 
   const int64_t FP = F * P;
   int64_t nb = (FP + 255) / 256;
   if (nb > 2048) nb = 2048;
+  if (dtype == PM_F32) {
+    hipLaunchKernelGGL((unpack_output_kernel<float>), dim3((unsigned)nb), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)y, (float*)out, (int)C, FP);
+    return check_launch();
+  }
   PM_DISPATCH_DTYPE(dtype, T,
                     hipLaunchKernelGGL((unpack_output_kernel<T>), dim3((unsigned)nb), dim3(256), 0,
                                        (hipStream_t)stream, (const T*)y, (T*)out, (int)C, FP);

@@ -1,11 +1,30 @@
 // HBM-bound normalisation kernels on channels-last activations: GroupNorm(32) with optional fused
 // SiLU (two passes: deterministic partial statistics, then apply) and LayerNorm.  All loads/stores
 // are 16 bytes per lane along the contiguous channel axis; statistics are f32.
+#include <type_traits>
 #include "common.hpp"
 
 namespace pm {
 
-constexpr int GN_ROWS_PER_CHUNK = 512;
+constexpr int GN_ROWS_PER_CHUNK = 64;  // many small chunks: the stats pass must fill 256 CUs
+
+// eight consecutive channels as f32, from a 16-bit or f32 row
+template <typename TI> __device__ __forceinline__ void load8(const TI* p, float (&v)[8]) {
+  if constexpr (std::is_same<TI, float>::value) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = a[e];
+      v[e + 4] = b[e];
+    }
+  } else {
+    Pack8<TI> t;
+    t.u = ld_global16(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = to_f32(t.e[e]);
+  }
+}
 
 __host__ __device__ inline int gn_threads(int CV) {
   // threads per block = CV * k (every thread keeps a fixed 8-channel column), <= 1024
@@ -14,11 +33,11 @@ __host__ __device__ inline int gn_threads(int CV) {
   return CV * k;
 }
 
-// grid (nchunks, NI); block gn_threads(C/8)
-template <typename T>
-__global__ void gn_stats_kernel(const T* __restrict__ x, int64_t ldx, float* __restrict__ partials,
+// grid (nchunks, NI); block gn_threads(C/8); LDS [k][2][C] floats
+template <typename TI>
+__global__ void gn_stats_kernel(const TI* __restrict__ x, int64_t ldx, float* __restrict__ partials,
                                 int P, int C, int groups, int nchunks) {
-  extern __shared__ __attribute__((aligned(16))) float sh[];  // [2][C]
+  extern __shared__ __attribute__((aligned(16))) float sh[];
   const int CV = C >> 3;
   const int k = blockDim.x / CV;
   const int cv = threadIdx.x % CV, rlane = threadIdx.x / CV;
@@ -26,49 +45,46 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, int64_t ldx, float* __r
   const int r0 = chunk * GN_ROWS_PER_CHUNK;
   int r1 = r0 + GN_ROWS_PER_CHUNK;
   if (r1 > P) r1 = P;
-  const T* xp = x + ((int64_t)inst * P) * ldx + cv * 8;
+  const TI* xp = x + ((int64_t)inst * P) * ldx + cv * 8;
   float s[8], ss[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
   for (int r = r0 + rlane; r < r1; r += k) {
-    Pack8<T> t;
-    t.u = ld_global16(xp + (int64_t)r * ldx);
+    float v[8];
+    load8<TI>(xp + (int64_t)r * ldx, v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float v = to_f32(t.e[e]);
-      s[e] += v;
-      ss[e] = fmaf(v, v, ss[e]);
+      s[e] += v[e];
+      ss[e] = fmaf(v[e], v[e], ss[e]);
     }
   }
-  // reduce the k row-lanes per channel through LDS (fixed order => deterministic)
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sh[i] = 0.f;
-  __syncthreads();
-  for (int turn = 0; turn < k; ++turn) {
-    if (rlane == turn) {
+  // per-thread partials -> LDS [rlane][2][C]; then fixed-order reductions (deterministic)
+  float* mine = sh + (int64_t)rlane * 2 * C;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        sh[cv * 8 + e] += s[e];
-        sh[C + cv * 8 + e] += ss[e];
-      }
-    }
-    __syncthreads();
+  for (int e = 0; e < 8; ++e) {
+    mine[cv * 8 + e] = s[e];
+    mine[C + cv * 8 + e] = ss[e];
   }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) {
+    float a = sh[c];
+    for (int j = 1; j < k; ++j) a += sh[j * 2 * C + c];
+    sh[c] = a;
+  }
+  __syncthreads();
   const int cpg = C / groups;
-  if (threadIdx.x < groups) {
-    float a = 0.f, b = 0.f;
-    for (int c = 0; c < cpg; ++c) {
-      a += sh[threadIdx.x * cpg + c];
-      b += sh[C + threadIdx.x * cpg + c];
-    }
-    float* out = partials + (((int64_t)inst * nchunks + chunk) * groups + threadIdx.x) * 2;
-    out[0] = a;
-    out[1] = b;
+  if ((int)threadIdx.x < 2 * groups) {
+    const int g = threadIdx.x % groups, which = threadIdx.x / groups;
+    const float* src = sh + which * C + g * cpg;
+    float a = 0.f;
+    for (int c = 0; c < cpg; ++c) a += src[c];
+    partials[(((int64_t)inst * nchunks + chunk) * groups + g) * 2 + which] = a;
   }
 }
 
 // grid (nblocks, NI); block 256.  sh: scale[C], shift[C]
-template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int64_t ldx,
+template <typename TI, typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const TI* __restrict__ x, int64_t ldx,
                                                        const float* __restrict__ partials,
                                                        int nchunks, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
@@ -80,13 +96,29 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   float* shift = sh + C;
   float* gstat = sh + 2 * C;  // mean, rstd per group
   const int inst = blockIdx.y;
-  if ((int)threadIdx.x < groups) {
-    float a = 0.f, b = 0.f;
-    const float* pp = partials + ((int64_t)inst * nchunks * groups + threadIdx.x) * 2;
-    for (int c = 0; c < nchunks; ++c) {
-      a += pp[(int64_t)c * groups * 2];
-      b += pp[(int64_t)c * groups * 2 + 1];
+  // reduce the per-chunk partials: 256 threads = (groups*2 values) x (256/(2*groups) chunk lanes),
+  // each lane walks its chunks in order, then the lanes are summed in order (deterministic)
+  float* red = sh + 2 * C + 2 * groups;  // [lanes][2*groups]
+  {
+    const int nv = 2 * groups;
+    const int lanes = 256 / nv;
+    const int vidx = threadIdx.x % nv, ln = threadIdx.x / nv;
+    if (ln < lanes) {
+      const float* pp = partials + (int64_t)inst * nchunks * nv + vidx;
+      float a = 0.f;
+      for (int c = ln; c < nchunks; c += lanes) a += pp[(int64_t)c * nv];
+      red[ln * nv + vidx] = a;
     }
+    __syncthreads();
+    if ((int)threadIdx.x < nv) {
+      float a = 0.f;
+      for (int j = 0; j < lanes; ++j) a += red[j * nv + threadIdx.x];
+      red[threadIdx.x] = a;
+    }
+    __syncthreads();
+  }
+  if ((int)threadIdx.x < groups) {
+    const float a = red[threadIdx.x * 2], b = red[threadIdx.x * 2 + 1];
     const float mean = a * inv_count;
     float var = b * inv_count - mean * mean;
     if (var < 0.f) var = 0.f;
@@ -104,16 +136,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   __syncthreads();
   const int CV = C >> 3;
   const int64_t total = (int64_t)P * CV;
-  const T* xp = x + (int64_t)inst * P * ldx;
+  const TI* xp = x + (int64_t)inst * P * ldx;
   T* yp = y + (int64_t)inst * P * ldy;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t r = i / CV;
     const int cv = (int)(i - r * CV);
-    Pack8<T> t, o;
-    t.u = ld_global16(xp + r * ldx + cv * 8);
+    Pack8<T> o;
+    float t[8];
+    load8<TI>(xp + r * ldx + cv * 8, t);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float v = fmaf(to_f32(t.e[e]), scale[cv * 8 + e], shift[cv * 8 + e]);
+      float v = fmaf(t[e], scale[cv * 8 + e], shift[cv * 8 + e]);
       if (silu) v = silu_f(v);
       o.e[e] = from_f32<T>(v);
     }
@@ -122,8 +155,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 }
 
 // one wave per row, 4 rows per block; up to 8 vectors (64 channels... 4096) per lane
-template <typename T>
-__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int64_t ldx,
+template <typename TI, typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, int64_t ldx,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         T* __restrict__ y, int64_t ldy, int M, int C,
@@ -132,20 +165,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int CV = C >> 3;
-  const T* xp = x + (int64_t)row * ldx;
+  const TI* xp = x + (int64_t)row * ldx;
   float v[8][8];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int cv = lane + 64 * i;
     if (cv < CV) {
-      Pack8<T> t;
-      t.u = ld_global16(xp + cv * 8);
+      load8<TI>(xp + cv * 8, v[i]);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[i][e] = to_f32(t.e[e]);
-        s += v[i][e];
-      }
+      for (int e = 0; e < 8; ++e) s += v[i][e];
     }
   }
   const float mean = wave_sum(s) / (float)C;
@@ -191,35 +220,61 @@ extern "C" int64_t pm_groupnorm_nchunks(int64_t P, int64_t C) {
   return (P + GN_ROWS_PER_CHUNK - 1) / GN_ROWS_PER_CHUNK;
 }
 
-static int gn_check(int64_t NI, int64_t P, int64_t C, int groups, int64_t ldx) {
-  if (NI < 1 || P < 1 || C < 8 || (C & 7) || groups < 1 || groups > 256 || (C % groups)) return PM_E_SHAPE;
-  if ((C >> 3) > 1024 || (ldx & 7) || ldx < C || NI > 65535) return PM_E_SHAPE;
+static int gn_check(int64_t NI, int64_t P, int64_t C, int groups, int64_t ldx, int in_dtype) {
+  if (NI < 1 || P < 1 || C < 8 || (C & 7) || groups < 1 || groups > 128 || (C % groups)) return PM_E_SHAPE;
+  const int64_t amask = (in_dtype == PM_F32) ? 3 : 7;
+  if ((C >> 3) > 1024 || (ldx & amask) || ldx < C || NI > 65535) return PM_E_SHAPE;
   return PM_OK;
 }
 
-extern "C" int pm_groupnorm_stats(const void* x, int64_t ldx, float* partials, int64_t NI, int64_t P,
-                                  int64_t C, int groups, int dtype, void* stream) {
-  if (!x || !partials) return PM_E_NULL;
-  int rc = gn_check(NI, P, C, groups, ldx);
-  if (rc) return rc;
+// in_dtype in {F16, BF16, F32} x out_dtype in {F16, BF16}
+#define PM_DISPATCH_IN_OUT(in_dtype, out_dtype, TI, TO, ...)                                   \
+  do {                                                                                          \
+    if ((out_dtype) == PM_F16) {                                                                \
+      typedef pm::f16 TO;                                                                       \
+      if ((in_dtype) == PM_F16) { typedef pm::f16 TI; __VA_ARGS__; }                            \
+      else if ((in_dtype) == PM_F32) { typedef float TI; __VA_ARGS__; }                         \
+      else return PM_E_DTYPE;                                                                   \
+    } else if ((out_dtype) == PM_BF16) {                                                        \
+      typedef pm::bf16 TO;                                                                      \
+      if ((in_dtype) == PM_BF16) { typedef pm::bf16 TI; __VA_ARGS__; }                          \
+      else if ((in_dtype) == PM_F32) { typedef float TI; __VA_ARGS__; }                         \
+      else return PM_E_DTYPE;                                                                   \
+    } else {                                                                                    \
+      return PM_E_DTYPE;                                                                        \
+    }                                                                                           \
+  } while (0)
+
+template <typename TI>
+static int launch_stats(const void* x, int64_t ldx, float* partials, int64_t NI, int64_t P, int64_t C,
+                        int groups, hipStream_t stream) {
   const int nchunks = (int)pm_groupnorm_nchunks(P, C);
   const int threads = gn_threads((int)(C >> 3));
-  if (threads < groups) return PM_E_SHAPE;
+  if (threads < 2 * groups) return PM_E_SHAPE;
+  const int k = threads / (int)(C >> 3);
   dim3 grid(nchunks, (unsigned)NI);
-  const size_t shmem = 2 * C * sizeof(float);
-  PM_DISPATCH_DTYPE(dtype, T,
-                    hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(threads), shmem,
-                                       (hipStream_t)stream, (const T*)x, ldx, partials, (int)P,
-                                       (int)C, groups, nchunks);
-                    return check_launch());
+  const size_t shmem = (size_t)k * 2 * C * sizeof(float);
+  hipLaunchKernelGGL((gn_stats_kernel<TI>), grid, dim3(threads), shmem, stream, (const TI*)x, ldx,
+                     partials, (int)P, (int)C, groups, nchunks);
+  return check_launch();
+}
+
+extern "C" int pm_groupnorm_stats(const void* x, int64_t ldx, float* partials, int64_t NI, int64_t P,
+                                  int64_t C, int groups, int in_dtype, void* stream) {
+  if (!x || !partials) return PM_E_NULL;
+  int rc = gn_check(NI, P, C, groups, ldx, in_dtype);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (in_dtype == PM_F32) return launch_stats<float>(x, ldx, partials, NI, P, C, groups, st);
+  PM_DISPATCH_DTYPE(in_dtype, T, return launch_stats<T>(x, ldx, partials, NI, P, C, groups, st));
 }
 
 extern "C" int pm_groupnorm_apply(const void* x, int64_t ldx, const float* partials, int64_t nchunks,
                                   const float* gamma, const float* beta, void* y, int64_t ldy,
                                   int64_t NI, int64_t P, int64_t C, int groups, double count,
-                                  float eps, int silu, int dtype, void* stream) {
+                                  float eps, int silu, int in_dtype, int out_dtype, void* stream) {
   if (!x || !partials || !gamma || !beta || !y) return PM_E_NULL;
-  int rc = gn_check(NI, P, C, groups, ldx);
+  int rc = gn_check(NI, P, C, groups, ldx, in_dtype);
   if (rc) return rc;
   if ((ldy & 7) || ldy < C || nchunks < 1 || count <= 0) return PM_E_SHAPE;
   const int64_t vecs = P * (C >> 3);
@@ -228,24 +283,26 @@ extern "C" int pm_groupnorm_apply(const void* x, int64_t ldx, const float* parti
   if (nb > cap) nb = cap;
   if (nb < 1) nb = 1;
   dim3 grid((unsigned)nb, (unsigned)NI);
-  const size_t shmem = (2 * C + 2 * groups) * sizeof(float);
-  PM_DISPATCH_DTYPE(dtype, T,
-                    hipLaunchKernelGGL((gn_apply_kernel<T>), grid, dim3(256), shmem,
-                                       (hipStream_t)stream, (const T*)x, ldx, partials, (int)nchunks,
-                                       gamma, beta, (T*)y, ldy, (int)P, (int)C, groups,
-                                       (float)(1.0 / count), eps, silu);
-                    return check_launch());
+  const size_t shmem = (2 * C + 2 * groups + 256) * sizeof(float);
+  PM_DISPATCH_IN_OUT(in_dtype, out_dtype, TI, TO,
+                     hipLaunchKernelGGL((gn_apply_kernel<TI, TO>), grid, dim3(256), shmem,
+                                        (hipStream_t)stream, (const TI*)x, ldx, partials, (int)nchunks,
+                                        gamma, beta, (TO*)y, ldy, (int)P, (int)C, groups,
+                                        (float)(1.0 / count), eps, silu);
+                     return check_launch());
 }
 
 extern "C" int pm_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta,
-                            void* y, int64_t ldy, int64_t M, int64_t C, float eps, int dtype,
-                            void* stream) {
+                            void* y, int64_t ldy, int64_t M, int64_t C, float eps, int in_dtype,
+                            int out_dtype, void* stream) {
   if (!x || !gamma || !beta || !y) return PM_E_NULL;
-  if (M < 1 || C < 8 || (C & 7) || C > 4096 || (ldx & 7) || (ldy & 7) || ldx < C || ldy < C)
+  const int64_t amask = (in_dtype == PM_F32) ? 3 : 7;
+  if (M < 1 || C < 8 || (C & 7) || C > 4096 || (ldx & amask) || (ldy & 7) || ldx < C || ldy < C)
     return PM_E_SHAPE;
   dim3 grid((unsigned)((M + 3) / 4));
-  PM_DISPATCH_DTYPE(dtype, T,
-                    hipLaunchKernelGGL((layernorm_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
-                                       (const T*)x, ldx, gamma, beta, (T*)y, ldy, (int)M, (int)C, eps);
-                    return check_launch());
+  PM_DISPATCH_IN_OUT(in_dtype, out_dtype, TI, TO,
+                     hipLaunchKernelGGL((layernorm_kernel<TI, TO>), grid, dim3(256), 0,
+                                        (hipStream_t)stream, (const TI*)x, ldx, gamma, beta, (TO*)y, ldy,
+                                        (int)M, (int)C, eps);
+                     return check_launch());
 }

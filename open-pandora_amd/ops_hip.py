@@ -10,6 +10,7 @@ import torch
 from . import capi
 
 _DT = {torch.float16: capi.PM_F16, torch.bfloat16: capi.PM_BF16}
+_F32 = capi.PM_F32
 
 
 def _ptr(t):
@@ -34,60 +35,73 @@ class HipOps:
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
-    def _rows(self, t):
+    def _rows(self, t, f32_ok=False):
         """(row stride in elements) of a 2-D, last-dim-contiguous view."""
-        assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == self.dtype, (t.shape, t.stride(), t.dtype)
+        assert t.dim() == 2 and t.stride(1) == 1, (t.shape, t.stride())
+        assert t.dtype == self.dtype or (f32_ok and t.dtype == torch.float32), t.dtype
         return t.stride(0)
+
+    def _in_dt(self, t):
+        return _F32 if t.dtype == torch.float32 else self.dt
+
+    def _gemm_io(self, a, residual, out, M, n_out, stream):
+        """flags + output allocation shared by the GEMM family.  `stream=True`: the result belongs to
+        the f32 residual stream (f32 output and f32 residual); an f32 `a` is rounded while staging."""
+        flags = (capi.PM_FLAG_A_F32 if a.dtype == torch.float32 else 0) | (capi.PM_FLAG_OUT_F32 if stream else 0)
+        odt = torch.float32 if stream else self.dtype
+        if out is None:
+            out = self.empty(M, n_out, dtype=odt)
+        assert out.dtype == odt and out.stride(1) == 1
+        if residual is not None:
+            assert residual.dtype == odt and residual.stride(1) == 1, (residual.dtype, odt)
+        return flags, out
 
     def empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.dtype, device=self.device)
 
     # -- GEMM family -----------------------------------------------------------------------------
-    def gemm(self, a, w, bias=None, residual=None, act="none", out=None):
+    def gemm(self, a, w, bias=None, residual=None, act="none", out=None, stream=False):
         """out[M, N] = epi(a[M, K] @ w[N, K]^T); GEGLU halves N (weights pre-interleaved)."""
         M, K = a.shape
         N = w.shape[0]
         assert w.shape[1] == K and w.is_contiguous() and w.dtype == self.dtype
         n_out = N // 2 if act == "geglu" else N
-        if out is None:
-            out = self.empty(M, n_out)
-        rc = self.lib.pm_gemm(_ptr(a), self._rows(a), _ptr(w), K, _ptr(bias),
-                              _ptr(residual), self._rows(residual) if residual is not None else 0,
-                              _ptr(out), self._rows(out), M, N, K, capi.ACT_CODES[act], self.dt,
+        flags, out = self._gemm_io(a, residual, out, M, n_out, stream)
+        rc = self.lib.pm_gemm(_ptr(a), self._rows(a, True), _ptr(w), K, _ptr(bias),
+                              _ptr(residual), residual.stride(0) if residual is not None else 0,
+                              _ptr(out), out.stride(0), M, N, K, capi.ACT_CODES[act], flags, self.dt,
                               self._stream())
         capi.check(rc, f"pm_gemm M={M} N={N} K={K}")
         return out
 
-    def conv3x3(self, x, wp, bias, F, H, W, stride=1, upsample=False, residual=None, out=None):
+    def conv3x3(self, x, wp, bias, F, H, W, stride=1, upsample=False, residual=None, out=None, stream=False):
         """x [F*H*W, Cin] -> [F*Ho*Wo, Cout]; wp packed [Cout, 9*Cin]."""
         cin = x.shape[1]
         cout = wp.shape[0]
         assert x.shape[0] == F * H * W and wp.shape[1] == 9 * cin and wp.is_contiguous()
         hv, wv = (2 * H, 2 * W) if upsample else (H, W)
         ho, wo = (hv + stride - 1) // stride, (wv + stride - 1) // stride
-        if out is None:
-            out = self.empty(F * ho * wo, cout)
-        rc = self.lib.pm_conv2d_3x3(_ptr(x), self._rows(x), _ptr(wp), _ptr(bias), _ptr(residual),
-                                    self._rows(residual) if residual is not None else 0, _ptr(out),
-                                    self._rows(out), F, H, W, cin, cout, stride, int(upsample),
-                                    _ptr(self.zero_page), self.dt, self._stream())
+        flags, out = self._gemm_io(x, residual, out, F * ho * wo, cout, stream)
+        rc = self.lib.pm_conv2d_3x3(_ptr(x), self._rows(x, True), _ptr(wp), _ptr(bias), _ptr(residual),
+                                    residual.stride(0) if residual is not None else 0, _ptr(out),
+                                    out.stride(0), F, H, W, cin, cout, stride, int(upsample),
+                                    _ptr(self.zero_page), flags, self.dt, self._stream())
         capi.check(rc, f"pm_conv2d_3x3 F={F} H={H} W={W} Cin={cin} Cout={cout}")
         return out
 
-    def conv_t3(self, x, wp, bias, F, P, residual=None, halo_lo=None, halo_hi=None, out=None):
+    def conv_t3(self, x, wp, bias, F, P, residual=None, halo_lo=None, halo_hi=None, out=None, stream=False):
         """3-tap conv over frames: x [F*P, Cin] -> [F*P, Cout]; wp packed [Cout, 3*Cin]."""
         cin = x.shape[1]
         cout = wp.shape[0]
         assert x.shape[0] == F * P and wp.shape[1] == 3 * cin and wp.is_contiguous()
         for h in (halo_lo, halo_hi):
             assert h is None or (h.shape == (P, cin) and self._rows(h) == self._rows(x))
-        if out is None:
-            out = self.empty(F * P, cout)
-        rc = self.lib.pm_conv_temporal_k3(_ptr(x), self._rows(x), _ptr(halo_lo), _ptr(halo_hi),
+        flags, out = self._gemm_io(x, residual, out, F * P, cout, stream)
+        rc = self.lib.pm_conv_temporal_k3(_ptr(x), self._rows(x, True), _ptr(halo_lo), _ptr(halo_hi),
                                           _ptr(wp), _ptr(bias), _ptr(residual),
-                                          self._rows(residual) if residual is not None else 0,
-                                          _ptr(out), self._rows(out), F, P, cin, cout,
-                                          _ptr(self.zero_page), self.dt, self._stream())
+                                          residual.stride(0) if residual is not None else 0,
+                                          _ptr(out), out.stride(0), F, P, cin, cout,
+                                          _ptr(self.zero_page), flags, self.dt, self._stream())
         capi.check(rc, f"pm_conv_temporal_k3 F={F} P={P} Cin={cin} Cout={cout}")
         return out
 
@@ -109,8 +123,8 @@ class HipOps:
         assert P * NI == M
         nch = self.lib.pm_groupnorm_nchunks(P, C)
         part = torch.empty(NI, nch, groups, 2, dtype=torch.float32, device=self.device)
-        rc = self.lib.pm_groupnorm_stats(_ptr(x), self._rows(x), _ptr(part), NI, P, C, groups,
-                                         self.dt, self._stream())
+        rc = self.lib.pm_groupnorm_stats(_ptr(x), self._rows(x, True), _ptr(part), NI, P, C, groups,
+                                         self._in_dt(x), self._stream())
         capi.check(rc, f"pm_groupnorm_stats NI={NI} P={P} C={C}")
         return part
 
@@ -121,20 +135,20 @@ class HipOps:
             count = float(P * (C // groups))
         if out is None:
             out = self.empty(M, C)
-        rc = self.lib.pm_groupnorm_apply(_ptr(x), self._rows(x), _ptr(partials), partials.shape[1],
+        rc = self.lib.pm_groupnorm_apply(_ptr(x), self._rows(x, True), _ptr(partials), partials.shape[1],
                                          _ptr(gamma), _ptr(beta), _ptr(out), self._rows(out), NI, P,
-                                         C, groups, float(count), float(eps), int(silu), self.dt,
-                                         self._stream())
+                                         C, groups, float(count), float(eps), int(silu),
+                                         self._in_dt(x), self.dt, self._stream())
         capi.check(rc, f"pm_groupnorm_apply NI={NI} P={P} C={C}")
         return out
 
     def groupnorm(self, x, gamma, beta, eps, NI, silu, groups=32, stats_reduce=None, out=None):
-        """GroupNorm over NI instances of [P, C]; stats_reduce (frame-sharded mode) maps the partial
-        sums f32 [NI, groups, 2] to their all-rank totals and returns (totals, total_count)."""
+        """GroupNorm over NI instances of [P, C]; stats_reduce(partial [NI, groups, 2], local_count)
+        (frame-sharded mode) returns the all-rank totals and the total element count per group."""
         part = self.groupnorm_stats(x, NI, groups)
         count = None
         if stats_reduce is not None:
-            tot, count = stats_reduce(part.sum(dim=1))
+            tot, count = stats_reduce(part.sum(dim=1), (x.shape[0] // NI) * (x.shape[1] // groups))
             part = tot.reshape(NI, 1, groups, 2).contiguous()
         return self.groupnorm_apply(x, part, gamma, beta, eps, NI, silu, count, groups, out)
 
@@ -142,8 +156,9 @@ class HipOps:
         M, C = x.shape
         if out is None:
             out = self.empty(M, C)
-        rc = self.lib.pm_layernorm(_ptr(x), self._rows(x), _ptr(gamma), _ptr(beta), _ptr(out),
-                                   self._rows(out), M, C, float(eps), self.dt, self._stream())
+        rc = self.lib.pm_layernorm(_ptr(x), self._rows(x, True), _ptr(gamma), _ptr(beta), _ptr(out),
+                                   self._rows(out), M, C, float(eps), self._in_dt(x), self.dt,
+                                   self._stream())
         capi.check(rc, f"pm_layernorm M={M} C={C}")
         return out
 
@@ -197,7 +212,7 @@ class HipOps:
         rc = self.lib.pm_ddim_update(_ptr(x), _ptr(e_c), _ptr(e_u), _ptr(noise), _ptr(x_prev),
                                      _ptr(x0), x.numel(), float(cfg), float(sqrt_ac),
                                      float(sqrt_1mac), float(rescale), float(sqrt_a_prev),
-                                     float(dir_coef), float(sigma), self.dt, self._stream())
+                                     float(dir_coef), float(sigma), self._in_dt(e_c), self._stream())
         capi.check(rc, "pm_ddim_update")
         return x_prev, x0
 
@@ -212,10 +227,10 @@ class HipOps:
         return y
 
     def unpack_output(self, y, F, P):
-        """[F*P, C] -> [C, F, P] (same dtype)."""
+        """[F*P, C] -> [C, F, P] (same dtype as y: 16-bit or f32)."""
         C = y.shape[1]
         assert y.is_contiguous()
-        out = self.empty(C, F, P)
-        rc = self.lib.pm_unpack_output(_ptr(y), _ptr(out), C, F, P, self.dt, self._stream())
+        out = self.empty(C, F, P, dtype=y.dtype)
+        rc = self.lib.pm_unpack_output(_ptr(y), _ptr(out), C, F, P, self._in_dt(y), self._stream())
         capi.check(rc, "pm_unpack_output")
         return out

@@ -5,7 +5,8 @@ device and torch version), mapped to a uniform distribution with a per-tensor st
   * matrices / conv kernels: std = 1 / sqrt(fan_in)  (every tensor, INCLUDING the ones the
     reference zero-initialises - with those left at zero the U-Net output is exactly 0 and any
     parity check is vacuous, SURVEY §0.4);
-  * norm scales: 1 + 0.1 u;  norm shifts / biases: 0.05 u.
+  * norm scales: 1 + 0.1 u;  norm shifts / biases: 0.05 u;
+  * every parameter is snapped to the bf16 grid (and is f16-exact), like a bf16-trained checkpoint.
 """
 import zlib
 
@@ -35,6 +36,14 @@ def uniform_pm1(n, seed, name, device="cpu"):
     return u * 2.0 - 1.0
 
 
+def _checkpoint_grid(v):
+    """Snap to values that are exact in bf16 AND f16 (bf16 mantissa, |v| >= 2^-14 or 0), as the weights
+    of a bf16-trained checkpoint are: the 16-bit product and the f32 reference then consume bit-identical
+    parameters and a parity run measures the arithmetic, not a weight re-quantisation."""
+    v = v.to(torch.bfloat16).to(torch.float32)
+    return torch.where(v.abs() < 2.0 ** -14, torch.zeros_like(v), v)
+
+
 def synth_tensor(name, shape, seed, device="cpu"):
     n = 1
     for s in shape:
@@ -42,10 +51,12 @@ def synth_tensor(name, shape, seed, device="cpu"):
     u = uniform_pm1(n, seed, name, device).reshape(shape)
     if len(shape) >= 2:
         fan_in = n // shape[0]
-        return u * (3.0 ** 0.5) * (fan_in ** -0.5)
-    if name.endswith("weight"):  # GroupNorm / LayerNorm scale
-        return 1.0 + 0.1 * u
-    return 0.05 * u
+        v = u * (3.0 ** 0.5) * (fan_in ** -0.5)
+    elif name.endswith("weight"):  # GroupNorm / LayerNorm scale
+        v = 1.0 + 0.1 * u
+    else:
+        v = 0.05 * u
+    return _checkpoint_grid(v)
 
 
 def synth_state_dict(module_or_shapes, seed=20230211, device="cpu", dtype=torch.float32):

@@ -8,6 +8,11 @@ including the reference's `temopral_conv` spelling), so checkpoints and the YAML
 * activations never exist as NCHW: they are channels-last token matrices [frames*H*W, C], which makes
   every Linear a plain GEMM, every 3x3 / temporal conv an implicit GEMM, and removes all the
   `(b f) c h w <-> b c f h w` shuffles around the temporal modules (openaimodel3d.py:36-48);
+* the residual stream (the tensor every ResBlock / transformer block adds into) is kept in f32 in
+  HBM; branch operands (normalised activations, q/k/v, GEGLU products) are 16-bit.  16-bit rounding
+  then happens once per branch operand instead of once per residual add (~180 adds per forward), which
+  is what brings a whole forward to ~1e-3 of the f32 reference; the price is 2 extra bytes per element
+  on the norm reads of the stream (HBM-bound kernels, ~1 % of a step);
 * every op goes through an op table (`self.ops`): `HipOps` (gfx950 kernels over the C-ABI) in
   production.  nn.Module parameters are only the reference-format storage; `prepare()` builds the
   kernel-side packed copies (fused qkv, tap-major conv weights, interleaved GEGLU rows).
@@ -353,10 +358,11 @@ class UNetModel(nn.Module):
         P = c.H * c.W
         h = self._gn(c, x, e["gn1"], 1e-5, True, True)
         lo, hi = e["emb_slice"]
-        h = ops.conv3x3(h, e["conv1"], c.emb_bias[lo:hi], c.F, c.H, c.W)
+        # conv outputs that only feed a GroupNorm stay f32 too (one rounding less per branch)
+        h = ops.conv3x3(h, e["conv1"], c.emb_bias[lo:hi], c.F, c.H, c.W, stream=True)
         h = self._gn(c, h, e["gn2"], 1e-5, True, True)
-        skip = x if e["skip"] is None else ops.gemm(x, e["skip"][0], e["skip"][1])
-        h = ops.conv3x3(h, e["conv2"][0], e["conv2"][1], c.F, c.H, c.W, residual=skip)
+        skip = x if e["skip"] is None else ops.gemm(x, e["skip"][0], e["skip"][1], stream=True)
+        h = ops.conv3x3(h, e["conv2"][0], e["conv2"][1], c.F, c.H, c.W, residual=skip, stream=True)
         if mod.use_temporal_conv:
             ident = h
             for i, (gb, wp, b) in enumerate(e["tconv"]):
@@ -364,7 +370,8 @@ class UNetModel(nn.Module):
                 lo_h = hi_h = None
                 if c.fp is not None:
                     lo_h, hi_h = c.fp.exchange_halo(t, P)
-                h = ops.conv_t3(t, wp, b, c.F, P, residual=ident if i == 3 else None, halo_lo=lo_h, halo_hi=hi_h)
+                h = ops.conv_t3(t, wp, b, c.F, P, residual=ident if i == 3 else None, halo_lo=lo_h, halo_hi=hi_h,
+                                stream=True)
         return h
 
     def _block(self, c, e, h, mod, temporal):
@@ -393,17 +400,17 @@ class UNetModel(nn.Module):
                     kv_i = ops.gemm(c.ctx_img, e["a2_kv_ip"]).view(c.F, -1, 2 * inner)
                     k2, v2 = kv_i[..., :inner], kv_i[..., inner:]
                 a = ops.attention(q, kv_t[..., :inner], kv_t[..., inner:], heads, k2, v2, 1.0)
-            h = ops.gemm(a.view(c.F * P, inner), *e[f"a{which}_out"], residual=h)
+            h = ops.gemm(a.view(c.F * P, inner), *e[f"a{which}_out"], residual=h, stream=True)
         y = ops.layernorm(h, *e["ln3"])
         g = ops.gemm(y, e["ff1"][0], e["ff1"][1], act="geglu")
-        return ops.gemm(g, e["ff2"][0], e["ff2"][1], residual=h)
+        return ops.gemm(g, e["ff2"][0], e["ff2"][1], residual=h, stream=True)
 
     def _transformer(self, c, mod, x, temporal):
         ops, e = c.ops, c.w[self._names[mod]]
         h = self._gn(c, x, e["norm"], 1e-6, False, not temporal)
-        h = ops.gemm(h, *e["proj_in"])
+        h = ops.gemm(h, *e["proj_in"], stream=True)  # the block's own residual stream (f32)
         h = self._block(c, e, h, mod, temporal)
-        return ops.gemm(h, *e["proj_out"], residual=x)
+        return ops.gemm(h, *e["proj_out"], residual=x, stream=True)
 
     def _run(self, c, seq, h):
         for layer in seq:
@@ -415,15 +422,15 @@ class UNetModel(nn.Module):
                 h = self._transformer(c, layer, h, True)
             elif isinstance(layer, Downsample):
                 wp, b = c.w[self._names[layer]]
-                h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W, stride=2)
+                h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W, stride=2, stream=True)
                 c.H, c.W = (c.H + 1) // 2, (c.W + 1) // 2
             elif isinstance(layer, Upsample):
                 wp, b = c.w[self._names[layer]]
-                h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W, upsample=True)
+                h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W, upsample=True, stream=True)
                 c.H, c.W = 2 * c.H, 2 * c.W
             elif isinstance(layer, nn.Conv2d):  # stem
                 wp, b = c.w["stem"]
-                h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W)
+                h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W, stream=True)
             else:
                 raise TypeError(type(layer))
         return h
@@ -443,7 +450,7 @@ class UNetModel(nn.Module):
     @torch.no_grad()
     def forward(self, x, timesteps, context=None, features_adapter=None, fs=None, **kwargs):
         """x (1, C_in, t_local, h, w), timesteps (1,), context (1, 77 + 16*T, 1024), fs (1,) ->
-        (1, C_out, t_local, h, w) in the op table's dtype.  In frame-sharded mode x holds this rank's
+        (1, C_out, t_local, h, w) in f32.  In frame-sharded mode x holds this rank's
         frames and `context` is the full-clip context (image tokens are sliced by `fp`)."""
         if self.ops is None:
             raise RuntimeError("UNetModel.bind(ops) must be called before forward (no implicit CPU fallback)")
@@ -485,5 +492,5 @@ class UNetModel(nn.Module):
             h = torch.cat([h, skip], dim=1)
             h = self._run(c, module, h)
         h = self._gn(c, h, c.w["out_gn"], 1e-5, True, True)
-        y = ops.conv3x3(h, c.w["out_conv"][0], c.w["out_conv"][1], c.F, c.H, c.W)
+        y = ops.conv3x3(h, c.w["out_conv"][0], c.w["out_conv"][1], c.F, c.H, c.W, stream=True)
         return ops.unpack_output(y, t, hh * ww).reshape(1, self.out_channels, t, hh, ww)

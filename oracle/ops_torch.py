@@ -41,7 +41,7 @@ class TorchOps:
         return t
 
     # -- GEMM family -----------------------------------------------------------------------------
-    def gemm(self, a, w, bias=None, residual=None, act="none", out=None):
+    def gemm(self, a, w, bias=None, residual=None, act="none", out=None, stream=False):
         y = _f(a) @ _f(w).t()
         if bias is not None:
             y = y + _f(bias)
@@ -56,7 +56,7 @@ class TorchOps:
             y = y + _f(residual)
         return self._out(y, out)
 
-    def conv3x3(self, x, wp, bias, F, H, W, stride=1, upsample=False, residual=None, out=None):
+    def conv3x3(self, x, wp, bias, F, H, W, stride=1, upsample=False, residual=None, out=None, stream=False):
         cin, cout = x.shape[1], wp.shape[0]
         xi = _f(x).reshape(F, H, W, cin).permute(0, 3, 1, 2)
         if upsample:
@@ -68,7 +68,7 @@ class TorchOps:
             y = y + _f(residual)
         return self._out(y, out)
 
-    def conv_t3(self, x, wp, bias, F, P, residual=None, halo_lo=None, halo_hi=None, out=None):
+    def conv_t3(self, x, wp, bias, F, P, residual=None, halo_lo=None, halo_hi=None, out=None, stream=False):
         cin, cout = x.shape[1], wp.shape[0]
         xi = _f(x).reshape(F, P, cin)
         lo = torch.zeros(1, P, cin) if halo_lo is None else _f(halo_lo).reshape(1, P, cin)
@@ -104,7 +104,7 @@ class TorchOps:
         else:
             xg = xi.reshape(NI, groups, -1)
             part = torch.stack([xg.sum(-1), (xg * xg).sum(-1)], -1)  # [NI, groups, 2]
-            tot, count = stats_reduce(part)
+            tot, count = stats_reduce(part, P * (C // groups))
             mean = tot[..., 0] / count
             var = (tot[..., 1] / count - mean * mean).clamp_min(0)
             y = (xg - mean[..., None]) * torch.rsqrt(var + eps)[..., None]

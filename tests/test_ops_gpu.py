@@ -283,3 +283,73 @@ def test_bad_arguments_raise(hip_ops_factory):
     w = torch.zeros(8, 72, dtype=torch.float16).cuda()
     with pytest.raises(PandoraKernelError):
         ops.gemm(a, w)
+
+
+# ---- f32 residual stream variants (PM_FLAG_A_F32 / PM_FLAG_OUT_F32, f32 norm inputs) -------------
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_f32_stream(hip_ops_factory, dtype):
+    """A operand from the f32 stream (rounded to 16 bit while staging), f32 residual and output."""
+    ops = hip_ops_factory(dtype)
+    M, N, K = 300, 320, 640
+    a32 = rnd(M, K, dtype=torch.float32, seed=1)
+    w = rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=2)
+    bias = rnd(N, dtype=torch.float32, seed=3)
+    res32 = rnd(M, N, dtype=torch.float32, scale=3.0, seed=4)
+    want = REF.gemm(a32.to(dtype), w, bias, res32)  # operand rounding is part of the contract
+    got = ops.gemm(a32.cuda(), w.cuda(), bias.cuda(), res32.cuda(), stream=True)
+    assert got.dtype == torch.float32
+    assert rel_err(got, want) <= 2e-5
+    got16 = ops.gemm(a32.cuda(), w.cuda(), bias.cuda())  # f32 A, 16-bit output
+    assert got16.dtype == dtype and rel_err(got16, REF.gemm(a32.to(dtype), w, bias)) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_f32_stream(hip_ops_factory, dtype):
+    ops = hip_ops_factory(dtype)
+    F, H, W, Cin, Cout = 2, 10, 16, 64, 128
+    x32 = rnd(F * H * W, Cin, dtype=torch.float32, seed=1)
+    w = rnd(Cout, Cin, 3, 3, dtype=dtype, scale=(9 * Cin) ** -0.5, seed=2)
+    bias = rnd(Cout, dtype=torch.float32, seed=3)
+    wp = packing.pack_conv3x3(w)
+    for stride, ups in ((2, False), (1, True), (1, False)):
+        want = REF.conv3x3(x32.to(dtype), wp, bias, F, H, W, stride, ups)
+        res32 = rnd(want.shape[0], Cout, dtype=torch.float32, seed=4)
+        got = ops.conv3x3(x32.cuda(), wp.cuda(), bias.cuda(), F, H, W, stride, ups, residual=res32.cuda(), stream=True)
+        assert got.dtype == torch.float32 and rel_err(got, want + res32) <= 2e-5
+    # temporal conv: 16-bit operand, f32 residual + output (TemporalConvBlock identity + x)
+    P, C = 50, 128
+    xt = rnd(4 * P, C, dtype=dtype, seed=5)
+    wt = packing.pack_conv_t3(rnd(C, C, 3, 1, 1, dtype=dtype, scale=(3 * C) ** -0.5, seed=6))
+    r32 = rnd(4 * P, C, dtype=torch.float32, seed=7)
+    want = REF.conv_t3(xt, wt, bias, 4, P, residual=r32)
+    got = ops.conv_t3(xt.cuda(), wt.cuda(), bias.cuda(), 4, P, residual=r32.cuda(), stream=True)
+    assert got.dtype == torch.float32 and rel_err(got, want) <= 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_norms_f32_input(hip_ops_factory, dtype):
+    ops = hip_ops_factory(dtype)
+    C = 320
+    gamma = 1 + 0.2 * rnd(C, dtype=torch.float32, seed=2)
+    beta = 0.3 * rnd(C, dtype=torch.float32, seed=3)
+    x = rnd(16 * 150, C, dtype=torch.float32, seed=1) * 2 + 0.7
+    for NI, silu in ((16, True), (1, False)):
+        want = REF.groupnorm(x, gamma, beta, 1e-5, NI, silu)
+        got = ops.groupnorm(x.cuda(), gamma.cuda(), beta.cuda(), 1e-5, NI, silu)
+        assert got.dtype == dtype and rel_err(got, want) <= TOL[dtype]
+    want = REF.layernorm(x[:333], gamma, beta)
+    got = ops.layernorm(x[:333].cuda(), gamma.cuda(), beta.cuda())
+    assert got.dtype == dtype and rel_err(got, want) <= TOL[dtype]
+
+
+def test_ddim_update_f32_model_output(hip_ops_factory):
+    ops = hip_ops_factory(torch.float16)
+    C, F, P = 4, 16, 60
+    x = rnd(C, F, P, dtype=torch.float32, seed=1)
+    ec, eu = rnd(C, F, P, dtype=torch.float32, seed=3), rnd(C, F, P, dtype=torch.float32, seed=4)
+    args = (4.0, 0.83, 0.55, 0.97, 0.9, 0.31, 0.0)
+    want_p, _ = REF.ddim_update(x, ec, eu, None, *args)
+    got_p, _ = ops.ddim_update(x.cuda(), ec.cuda(), eu.cuda(), None, *args)
+    assert rel_err(got_p, want_p) <= 1e-6
+    y = rnd(F * P, C, dtype=torch.float32, seed=6)
+    assert torch.equal(ops.unpack_output(y.cuda(), F, P).cpu(), REF.unpack_output(y, F, P))
