@@ -34,12 +34,12 @@ class TimedOps:
     def __getattr__(self, k):
         return getattr(self._ops, k)
 
-    def conv3x3(self, x, wp, bias, F, H, W, stride=1, upsample=False, residual=None, out=None):
+    def conv3x3(self, x, wp, bias, F, H, W, **kw):
         if not self.enabled:
-            return self._ops.conv3x3(x, wp, bias, F, H, W, stride, upsample, residual, out)
+            return self._ops.conv3x3(x, wp, bias, F, H, W, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        y = self._ops.conv3x3(x, wp, bias, F, H, W, stride, upsample, residual, out)
+        y = self._ops.conv3x3(x, wp, bias, F, H, W, **kw)
         e1.record()
         self.events.append((e0, e1))
         self.flops += 2.0 * y.shape[0] * y.shape[1] * wp.shape[1]

@@ -64,7 +64,16 @@ int pm_abi_version(void);
  */
 int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
             const void* residual, int64_t ldr, void* C, int64_t ldc, int64_t M, int64_t N,
-            int64_t K, int act, int flags, int dtype, void* stream);
+            int64_t K, int act, int flags, int dtype, void* workspace, size_t workspace_bytes,
+            void* stream);
+
+/* Split-K scratch.  GEMM-shaped calls whose output has too few 128x128 tiles to fill 256 CUs (the
+ * deep U-Net levels: M = 640..2560 rows, K up to 23040) split the K loop over several workgroups that
+ * write f32 partial slabs into `workspace`, followed by one reduce pass that applies the epilogue.
+ * pm_gemm_workspace_bytes returns the bytes that call shape would use (0 = never splits); a NULL or
+ * too small workspace is legal everywhere and simply disables splitting.  For the conv entry points
+ * M = F*Ho*Wo, N = Cout, K = 9*Cin (3*Cin for the temporal conv). */
+size_t pm_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int act);
 
 /* ------------------------------------------------------------------------------------------------
  * pm_conv2d_3x3: implicit-GEMM 3x3 convolution, padding 1, on channels-last frames.
@@ -79,7 +88,8 @@ int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float*
 int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const float* bias,
                   const void* residual, int64_t ldr, void* y, int64_t ldy, int64_t F, int64_t H,
                   int64_t W, int64_t Cin, int64_t Cout, int stride, int upsample2x,
-                  const void* zero_page, int flags, int dtype, void* stream);
+                  const void* zero_page, int flags, int dtype, void* workspace,
+                  size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * pm_conv_temporal_k3: Conv3d kernel (3,1,1), padding (1,0,0) = 3-tap conv along the frame axis.
@@ -92,7 +102,8 @@ int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const float* bias,
 int pm_conv_temporal_k3(const void* x, int64_t ldx, const void* halo_lo, const void* halo_hi,
                         const void* Wp, const float* bias, const void* residual, int64_t ldr,
                         void* y, int64_t ldy, int64_t F, int64_t P, int64_t Cin, int64_t Cout,
-                        const void* zero_page, int flags, int dtype, void* stream);
+                        const void* zero_page, int flags, int dtype, void* workspace,
+                  size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm(32 groups) on channels-last data, optional fused SiLU.

@@ -4,7 +4,7 @@ The product path has no fallback: if the library is missing or a call fails, thi
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpandora_mi355x.so")
@@ -19,13 +19,15 @@ SIGNATURES = {
     "pm_strerror": (c_char_p, [c_int]),
     "pm_abi_version": (c_int, []),
     "pm_gemm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
-                        c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+                        c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_size_t,
+                        c_void_p]),
+    "pm_gemm_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
     "pm_conv2d_3x3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                               c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
-                              c_void_p, c_int, c_int, c_void_p]),
+                              c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "pm_conv_temporal_k3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64,
-                                    c_int64, c_void_p, c_int, c_int, c_void_p]),
+                                    c_int64, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "pm_groupnorm_nchunks": (c_int64, [c_int64, c_int64]),
     "pm_groupnorm_stats": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int,
                                    c_int, c_void_p]),

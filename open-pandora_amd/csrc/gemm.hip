@@ -4,16 +4,18 @@
 //   C[M, N] = epi(A[M, K] . W[N, K]^T),  f32 accumulate on v_mfma_f32_16x16x32_{f16,bf16}.
 //
 // Tiling: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 MFMA
-// blocks), BK = 64.  A and W tiles are staged global -> VGPR -> LDS (issue-early / write-late, one
-// barrier per K-tile, two LDS buffers); LDS rows are 128 B with the 16-byte chunk index XOR-ed by
-// (row & 7) so the ds_read_b128 fragment reads spread over the banks.  The epilogue goes through LDS
+// blocks), BK = 64, two LDS buffers, one barrier per K-tile.  16-bit A and W tiles go global -> LDS by
+// DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write; the im2col gather and the padding
+// are per-lane SOURCE addresses); an f32 A operand (residual stream) is staged through registers and
+// rounded on the way.  LDS rows are 128 B with the 16-byte chunk index XOR-ed by (row & 7) - applied
+// on the source side - so the ds_read_b128 fragment reads spread over the banks.  The epilogue goes through LDS
 // (f32) so that residual loads and output stores are full 16-byte row segments.
 #include <type_traits>
 #include "common.hpp"
 
 namespace pm {
 
-enum { A_DENSE = 0, A_CONV3X3 = 1, A_CONVT3 = 2 };
+enum { A_DENSE = 0, A_CONV3X3 = 1, A_CONVT3 = 2, A_CONV3X3_FAST = 3 };
 
 struct GemmParams {
   const void* A;
@@ -29,6 +31,8 @@ struct GemmParams {
   int act;
   int out32;
   int ntiles;
+  int splits, ktps;  // split-K: number of K slices and K-tiles per slice
+  float* ws;         // split-K partial slabs [splits][M][N] f32
   // conv3x3
   int Hin, Win, Hv, Wv, Cin, Ho, Wo, stride, ups;
   // temporal conv
@@ -42,6 +46,9 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 constexpr int STAGE_LD = 132;            // f32 staging row stride (floats)
 
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of tiles so that
   // neighbouring tiles (same A row panel) share one L2.  Bijective for any nwg.
@@ -53,6 +60,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 template <typename T, int AMODE, bool A32>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   typedef typename std::conditional<A32, float, T>::type TA;  // storage type of the A operand
+  constexpr int ES = sizeof(TA);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const As = smem;                    // [2][TILE_BYTES]
   char* const Bs = smem + 2 * TILE_BYTES;   // [2][TILE_BYTES]
@@ -63,118 +71,157 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fq = lane >> 4;
 
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int wg0 = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = wg0 % p.splits;
+  const int wg = wg0 / p.splits;
   const int mt = wg / p.ntiles, nt = wg - mt * p.ntiles;
   const int m0 = mt * BM, n0 = nt * BN;
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int kt0 = split * p.ktps;
+  const int kt1 = (kt0 + p.ktps < nk_all) ? kt0 + p.ktps : nk_all;
 
-  const TA* __restrict__ Ag = reinterpret_cast<const TA*>(p.A);
-  const T* __restrict__ Wg = reinterpret_cast<const T*>(p.Wt);
-  const TA* zero = reinterpret_cast<const TA*>(p.zero);
-  const T* zero_w = reinterpret_cast<const T*>(p.zero);
+  const char* const Ab = reinterpret_cast<const char*>(p.A);
+  const char* const Wb = reinterpret_cast<const char*>(p.Wt);
+  const char* const zero = reinterpret_cast<const char*>(p.zero);
 
-  // ---- loader state: this thread stages chunk `lc` (8 elements) of rows lr + 32*j ----
-  const int lc = tid & 7;
+  // ---- loader state.  This thread stages rows lr + 32*j, filling the PHYSICAL 16-byte slot tid & 7
+  // of each 128-byte LDS row.  The XOR swizzle is applied on the SOURCE side: the lane fetches logical
+  // k-chunk lc = slot ^ (row & 7) (row & 7 == lr & 7 for all four rows), so that the LDS image is
+  // lane-linear, which is what a direct global->LDS DMA (global_load_lds_dwordx4) writes.
+  // Addresses are kept as (wave-uniform 64-bit base that walks K) + (constant 32-bit lane offset) so the
+  // main loop spends SALU, not VALU, on them: the kernel is otherwise VALU-issue-bound next to the MFMAs.
   const int lr = tid >> 3;
-  const TA* a_base[4];
-  const T* b_base[4];
-  int a_y[4], a_x[4];  // conv3x3: iy0, ix0 ; convt3: frame, unused
+  const int lc = (tid & 7) ^ (lr & 7);
+  uint32_t b_off[4], a_off[4];
+  int a_y[4], a_x[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     int m = m0 + lr + 32 * j;
     if (m > p.M - 1) m = p.M - 1;
     int n = n0 + lr + 32 * j;
     if (n > p.N - 1) n = p.N - 1;
-    b_base[j] = Wg + (int64_t)n * p.ldw;
+    b_off[j] = (uint32_t)(((int64_t)n * p.ldw + lc * 8) * 2);
     if (AMODE == A_DENSE) {
-      a_base[j] = Ag + (int64_t)m * p.lda;
+      a_off[j] = (uint32_t)(((int64_t)m * p.lda + lc * 8) * ES);
       a_y[j] = a_x[j] = 0;
-    } else if (AMODE == A_CONV3X3) {
+    } else if (AMODE == A_CONV3X3 || AMODE == A_CONV3X3_FAST) {
       const int hw = p.Ho * p.Wo;
       const int f = m / hw;
       const int rem = m - f * hw;
       const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      a_base[j] = Ag + (int64_t)f * p.Hin * p.Win * p.lda;
-      a_y[j] = oy * p.stride - 1;
-      a_x[j] = ox * p.stride - 1;
+      a_y[j] = oy * p.stride;  // tap (dy, dx) reads virtual pixel (a_y + dy - 1, a_x + dx - 1)
+      a_x[j] = ox * p.stride;
+      if (AMODE == A_CONV3X3_FAST)  // no upsample: offset of the centre tap, the tap shift is uniform
+        a_off[j] = (uint32_t)((((int64_t)f * p.Hin + a_y[j]) * p.Win + a_x[j]) * p.lda * ES + lc * 8 * ES);
+      else
+        a_off[j] = (uint32_t)((int64_t)f * p.Hin * p.Win * p.lda * ES);
     } else {
       const int f = m / p.P;
       const int pix = m - f * p.P;
-      a_base[j] = Ag + (int64_t)pix * p.lda;  // + frame * P * lda added per tap
+      a_off[j] = (uint32_t)((((int64_t)f * p.P + pix) * p.lda + lc * 8) * ES);
       a_y[j] = f;
       a_x[j] = pix;
     }
   }
-  // running (tap, channel) of this thread's chunk for the conv loaders
-  int tap = 0, ch = lc * 8;
+  // (tap, channel) position of the K walk.  Fast modes: one tap per K-tile (Cin % 64 == 0), tracked as
+  // wave-uniform scalars.  General conv (stem Cin = 8, nearest-x2 upsample): per-lane.
+  int tap_s = 0, ch_s = 0;       // uniform: tap and first channel of the current K-tile
+  int tap_l = 0, ch_l = lc * 8;  // per-lane (A_CONV3X3 only)
   if (AMODE != A_DENSE) {
-    tap = ch / p.Cin;
-    ch -= tap * p.Cin;
+    tap_s = (kt0 * BK) / p.Cin;
+    ch_s = kt0 * BK - tap_s * p.Cin;
+    const int k_l = kt0 * BK + lc * 8;
+    tap_l = k_l / p.Cin;
+    ch_l = k_l - tap_l * p.Cin;
   }
 
-  u32x4 ra[4], ra_hi[4], rb[4];  // ra_hi: second half of an f32 A chunk (A32 only)
-  auto load_tile = [&](int kt) {
-    const int k = kt * BK + lc * 8;
-    const bool kin = k < p.K;
+  u32x4 ra[4], ra_hi[4], rb[4];  // register staging (A32 only); ra_hi: second half of an f32 chunk
+  // issue the loads of K-tile kt (tiles are requested in increasing order) into LDS buffer `buf`
+  auto load_tile = [&](int kt, int buf) {
+    const int kb = kt * BK;
+    const bool kin_l = kb + lc * 8 < p.K;  // only the general conv mode can have a K tail
+    const char* wb = Wb + (int64_t)kb * 2;
+    const char* ab = Ab;
+    int dy = 0, dx = 0;
+    if (AMODE == A_DENSE) {
+      ab = Ab + (int64_t)kb * ES;
+    } else if (AMODE == A_CONV3X3_FAST) {
+      dy = tap_s / 3;
+      dx = tap_s - dy * 3;
+      ab = Ab + ((int64_t)((dy - 1) * p.Win + (dx - 1)) * p.lda + ch_s) * ES;
+    } else if (AMODE == A_CONVT3) {
+      ab = Ab + ((int64_t)(tap_s - 1) * p.P * p.lda + ch_s) * ES;
+    } else {
+      dy = tap_l / 3;
+      dx = tap_l - dy * 3;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const TA* src;
+      const char* src;
       if (AMODE == A_DENSE) {
-        src = kin ? a_base[j] + k : zero;
-      } else if (AMODE == A_CONV3X3) {
-        const int dy = tap / 3, dx = tap - dy * 3;
-        int iy = a_y[j] + dy, ix = a_x[j] + dx;
-        const bool ok = kin && iy >= 0 && iy < p.Hv && ix >= 0 && ix < p.Wv;
+        src = ab + a_off[j];
+      } else if (AMODE == A_CONV3X3_FAST) {
+        const bool ok = (unsigned)(a_y[j] + dy - 1) < (unsigned)p.Hv && (unsigned)(a_x[j] + dx - 1) < (unsigned)p.Wv;
+        src = ok ? ab + a_off[j] : zero;
+      } else if (AMODE == A_CONVT3) {
+        const int sf = a_y[j] + tap_s - 1;
+        if (sf < 0)
+          src = p.halo_lo ? reinterpret_cast<const char*>(p.halo_lo) + ((int64_t)a_x[j] * p.lda + ch_s + lc * 8) * ES : zero;
+        else if (sf >= p.F)
+          src = p.halo_hi ? reinterpret_cast<const char*>(p.halo_hi) + ((int64_t)a_x[j] * p.lda + ch_s + lc * 8) * ES : zero;
+        else
+          src = ab + a_off[j];
+      } else {
+        int iy = a_y[j] + dy - 1, ix = a_x[j] + dx - 1;
+        const bool ok = kin_l && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv;
         if (p.ups) {
           iy >>= 1;
           ix >>= 1;
         }
-        src = ok ? a_base[j] + ((int64_t)iy * p.Win + ix) * p.lda + ch : zero;
-      } else {
-        const int sf = a_y[j] + tap - 1;
-        if (!kin) {
-          src = zero;
-        } else if (sf < 0) {
-          src = p.halo_lo ? reinterpret_cast<const TA*>(p.halo_lo) + (int64_t)a_x[j] * p.lda + ch
-                          : zero;
-        } else if (sf >= p.F) {
-          src = p.halo_hi ? reinterpret_cast<const TA*>(p.halo_hi) + (int64_t)a_x[j] * p.lda + ch
-                          : zero;
-        } else {
-          src = a_base[j] + (int64_t)sf * p.P * p.lda + ch;
-        }
+        src = ok ? Ab + a_off[j] + (((int64_t)iy * p.Win + ix) * p.lda + ch_l) * ES : zero;
       }
-      ra[j] = ld_global16(src);
-      if (A32) ra_hi[j] = ld_global16(src + 4);
-      rb[j] = ld_global16(kin ? b_base[j] + k : zero_w);
+      const char* wsrc = (AMODE == A_CONV3X3 && !kin_l) ? zero : wb + b_off[j];
+      if constexpr (A32) {  // f32 stream operand: through registers (needs the f32 -> 16-bit rounding)
+        ra[j] = ld_global16(src);
+        ra_hi[j] = ld_global16(src + 16);
+        rb[j] = ld_global16(wsrc);
+      } else {  // 16-bit operands: DMA straight into the tile, 1 KiB per wave-instruction
+        const int dst = buf * TILE_BYTES + (32 * j + 8 * wave) * 128;
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(As + dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void*)wsrc, (lds_void*)(Bs + dst), 16, 0, 0);
+      }
     }
-    if (AMODE != A_DENSE) {  // advance to the next K-tile
-      ch += BK;
-      while (ch >= p.Cin) {
-        ch -= p.Cin;
-        ++tap;
+    if (AMODE != A_DENSE) {  // advance the (tap, channel) walk to the next K-tile
+      ch_s += BK;
+      if (ch_s >= p.Cin) {
+        ch_s -= p.Cin;
+        ++tap_s;
+      }
+      if (AMODE == A_CONV3X3) {
+        ch_l += BK;
+        while (ch_l >= p.Cin) {
+          ch_l -= p.Cin;
+          ++tap_l;
+        }
       }
     }
   };
   auto store_tile = [&](int buf) {
+    if constexpr (!A32) return;  // DMA path: the tile is already in flight to LDS
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int row = lr + 32 * j;
-      const int off = row * 128 + ((lc ^ (row & 7)) << 4);
-      if (A32) {  // f32 residual-stream operand: round to the MFMA input type while staging
-        union { u32x4 u; float f[4]; } lo, hi;
-        lo.u = ra[j];
-        hi.u = ra_hi[j];
-        Pack8<T> cv;
+      const int off = buf * TILE_BYTES + (lr + 32 * j) * 128 + ((tid & 7) << 4);
+      union { u32x4 u; float f[4]; } lo, hi;
+      lo.u = ra[j];
+      hi.u = ra_hi[j];
+      Pack8<T> cv;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          cv.e[e] = from_f32<T>(lo.f[e]);
-          cv.e[e + 4] = from_f32<T>(hi.f[e]);
-        }
-        *reinterpret_cast<u32x4*>(As + buf * TILE_BYTES + off) = cv.u;
-      } else {
-        *reinterpret_cast<u32x4*>(As + buf * TILE_BYTES + off) = ra[j];
+      for (int e = 0; e < 4; ++e) {
+        cv.e[e] = from_f32<T>(lo.f[e]);
+        cv.e[e + 4] = from_f32<T>(hi.f[e]);
       }
-      *reinterpret_cast<u32x4*>(Bs + buf * TILE_BYTES + off) = rb[j];
+      *reinterpret_cast<u32x4*>(As + off) = cv.u;
+      *reinterpret_cast<u32x4*>(Bs + off) = rb[j];
     }
   };
 
@@ -184,52 +231,54 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + BK - 1) / BK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
+  // fragment read offsets: row & 7 == fr & 7 for every MFMA block of this wave, so the swizzled slot
+  // depends on the k-step only; the block index becomes an immediate offset of the ds_read_b128
+  const int a_frag = (wm * 64 + fr) * 128, b_frag = (wn * 64 + fr) * 128;
+  const int slot0 = ((fq) ^ (fr & 7)) << 4, slot1 = ((4 + fq) ^ (fr & 7)) << 4;
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
-    const char* as = As + buf * TILE_BYTES;
-    const char* bs = Bs + buf * TILE_BYTES;
+  load_tile(kt0, 0);
+  store_tile(0);
+  __syncthreads();  // (hipcc drains vmcnt before the barrier, so the DMA'd tile is visible)
+
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
+    if (kt + 1 < kt1) load_tile(kt + 1, buf ^ 1);
+    const char* as = As + buf * TILE_BYTES + a_frag;
+    const char* bs = Bs + buf * TILE_BYTES + b_frag;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       Pack8<T> a[4], b[4];
-      const int chunk = ks * 4 + fq;
+      const int slot = ks ? slot1 : slot0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = wm * 64 + i * 16 + fr;
-        a[i].u = *reinterpret_cast<const u32x4*>(as + row * 128 + ((chunk ^ (row & 7)) << 4));
-      }
+      for (int i = 0; i < 4; ++i) a[i].u = *reinterpret_cast<const u32x4*>(as + i * 2048 + slot);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = wn * 64 + j * 16 + fr;
-        b[j].u = *reinterpret_cast<const u32x4*>(bs + row * 128 + ((chunk ^ (row & 7)) << 4));
-      }
+      for (int j = 0; j < 4; ++j) b[j].u = *reinterpret_cast<const u32x4*>(bs + j * 2048 + slot);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(a[i].v, b[j].v, acc[i][j]);
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+    if (kt + 1 < kt1) store_tile(buf ^ 1);
     __syncthreads();
   }
 
   // ---------------- epilogue ----------------
+  // split-K slices store raw f32 partials into their slab; bias/act/residual run in the reduce pass
+  const bool partial = p.splits > 1;
+  const float* bias_p = partial ? nullptr : p.bias;
+  const int act = partial ? PM_ACT_NONE : p.act;
   // acc[i][j][r] <-> m = wm*64 + i*16 + 4*fq + r,  n = wn*64 + j*16 + fr
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int n = n0 + wn * 64 + j * 16 + fr;
-    const float bv = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+    const float bv = (bias_p != nullptr && n < p.N) ? bias_p[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[i][j][r] += bv;
   }
-  const bool geglu = (p.act == PM_ACT_GEGLU);
-  if (p.act == PM_ACT_SILU) {
+  const bool geglu = (act == PM_ACT_GEGLU);
+  if (act == PM_ACT_SILU) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -252,10 +301,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   const int nbase = geglu ? (n0 >> 1) : n0;
   float* stage = reinterpret_cast<float*>(smem);  // [64][STAGE_LD]
   T* __restrict__ Cg = reinterpret_cast<T*>(p.C);
-  const T* __restrict__ Rg = reinterpret_cast<const T*>(p.R);
-  float* __restrict__ Cf = reinterpret_cast<float*>(p.C);          // PM_FLAG_OUT_F32: residual stream
-  const float* __restrict__ Rf = reinterpret_cast<const float*>(p.R);
-  const bool out32 = p.out32 != 0;
+  const T* __restrict__ Rg = partial ? nullptr : reinterpret_cast<const T*>(p.R);
+  float* __restrict__ Cf = partial ? p.ws + (int64_t)split * p.M * p.N
+                                   : reinterpret_cast<float*>(p.C);  // PM_FLAG_OUT_F32: residual stream
+  const float* __restrict__ Rf = partial ? nullptr : reinterpret_cast<const float*>(p.R);
+  const bool out32 = partial || p.out32 != 0;
+  const int64_t ldc = partial ? p.N : p.ldc;
   const int cpr = tw >> 3;         // 8-column chunks per row
   const int rpp = 256 / cpr;       // rows per pass
   const int scol = tid % cpr, srow = tid / cpr;
@@ -280,8 +331,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(stage + row * STAGE_LD + scol * 8 + 4);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         if (out32) {
-          float* cptr = Cf + (int64_t)m * p.ldc + n;
-          const bool full = (n + 8 <= nout) && ((p.ldc & 3) == 0);
+          float* cptr = Cf + (int64_t)m * ldc + n;
+          const bool full = (n + 8 <= nout) && ((ldc & 3) == 0);
           if (Rf != nullptr) {
             const float* rptr = Rf + (int64_t)m * p.ldr + n;
             if (full && ((p.ldr & 3) == 0)) {
@@ -303,8 +354,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
             for (int e = 0; e < 8 && n + e < nout; ++e) cptr[e] = v[e];
           }
         } else {
-          T* cptr = Cg + (int64_t)m * p.ldc + n;
-          const bool full = (n + 8 <= nout) && ((p.ldc & 7) == 0);
+          T* cptr = Cg + (int64_t)m * ldc + n;
+          const bool full = (n + 8 <= nout) && ((ldc & 7) == 0);
           if (Rg != nullptr) {
             const T* rptr = Rg + (int64_t)m * p.ldr + n;
             if (full && ((p.ldr & 7) == 0)) {
@@ -331,9 +382,69 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   }
 }
 
+// split-K second pass: out = epi(sum_s ws[s]) ; one thread per 4 consecutive columns
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
+  const int n4 = (p.N + 3) >> 2;
+  const int64_t total = (int64_t)p.M * n4;
+  const int64_t slab = (int64_t)p.M * p.N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / n4;
+    const int n = (int)(i - m * n4) * 4;
+    const float* src = p.ws + m * p.N + n;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = (n + 4 <= p.N) && ((p.N & 3) == 0);
+    for (int s = 0; s < p.splits; ++s) {
+      if (vec) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src + s * slab);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += t[e];
+      } else {
+        for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += src[s * slab + e];
+      }
+    }
+    for (int e = 0; e < 4 && n + e < p.N; ++e) {
+      float x = v[e] + (p.bias ? p.bias[n + e] : 0.f);
+      if (p.act == PM_ACT_SILU) x = silu_f(x);
+      if (p.out32) {
+        if (p.R) x += reinterpret_cast<const float*>(p.R)[m * p.ldr + n + e];
+        reinterpret_cast<float*>(p.C)[m * p.ldc + n + e] = x;
+      } else {
+        if (p.R) x += to_f32(reinterpret_cast<const T*>(p.R)[m * p.ldr + n + e]);
+        reinterpret_cast<T*>(p.C)[m * p.ldc + n + e] = from_f32<T>(x);
+      }
+    }
+  }
+}
+
+static int choose_splits(int64_t M, int64_t N, int64_t K, int act, int* ktps) {
+  const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  const int nk = (int)((K + BK - 1) / BK);
+  *ktps = nk;
+  if (act == PM_ACT_GEGLU || tiles >= 384 || nk < 8) return 1;
+  int64_t s = (512 + tiles - 1) / tiles;
+  if (s > nk / 4) s = nk / 4;
+  if (s > 32) s = 32;
+  if (s < 2) return 1;
+  *ktps = (int)((nk + s - 1) / s);
+  return (nk + *ktps - 1) / *ktps;
+}
+
+static void plan_split(GemmParams& p, void* workspace, size_t workspace_bytes) {
+  int ktps;
+  int s = choose_splits(p.M, p.N, p.K, p.act, &ktps);
+  if (s > 1 && (workspace == nullptr || workspace_bytes < (size_t)s * p.M * p.N * sizeof(float))) {
+    s = 1;  // no (or too small a) workspace: run unsplit
+    ktps = (p.K + BK - 1) / BK;
+  }
+  p.splits = s;
+  p.ktps = ktps;
+  p.ws = reinterpret_cast<float*>(workspace);
+}
+
 template <typename T, int AMODE, bool A32> static int launch1(const GemmParams& p, hipStream_t stream) {
   const int mtiles = (p.M + BM - 1) / BM;
-  const int grid = mtiles * p.ntiles;
+  const int grid = mtiles * p.ntiles * p.splits;
   static bool attr_set = false;  // idempotent; a benign race sets the same value twice
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, AMODE, A32>),
@@ -341,6 +452,12 @@ template <typename T, int AMODE, bool A32> static int launch1(const GemmParams& 
     attr_set = true;
   }
   hipLaunchKernelGGL((gemm_kernel<T, AMODE, A32>), dim3(grid), dim3(256), 4 * TILE_BYTES, stream, p);
+  if (p.splits > 1) {
+    const int64_t work = (int64_t)p.M * ((p.N + 3) / 4);
+    int64_t nb = (work + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)nb), dim3(256), 0, stream, p);
+  }
   return check_launch();
 }
 
@@ -364,7 +481,8 @@ using namespace pm;
 
 extern "C" int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                        const void* residual, int64_t ldr, void* C, int64_t ldc, int64_t M,
-                       int64_t N, int64_t K, int act, int flags, int dtype, void* stream) {
+                       int64_t N, int64_t K, int act, int flags, int dtype, void* workspace,
+                       size_t workspace_bytes, void* stream) {
   int rc = check_common(A, W, C, M, N, K, act);
   if (rc) return rc;
   if ((lda & ((flags & PM_FLAG_A_F32) ? 3 : 7)) || (ldw & 7) || lda < K || ldw < K) return PM_E_SHAPE;
@@ -378,13 +496,15 @@ extern "C" int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, c
   // A dense K tail (K % 64 != 0) reads chunk-wise: chunks with k >= K take `zero`; any 16 readable
   // bytes would poison the accumulator, so require a real zero source only when a tail exists.
   if (K % BK) return PM_E_SHAPE;  // all Linear layers on the path have K % 64 == 0
+  plan_split(p, workspace, workspace_bytes);
   PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_DENSE>(p, flags, (hipStream_t)stream)));
 }
 
 extern "C" int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const float* bias,
                              const void* residual, int64_t ldr, void* y, int64_t ldy, int64_t F,
                              int64_t H, int64_t W, int64_t Cin, int64_t Cout, int stride,
-                             int upsample2x, const void* zero_page, int flags, int dtype, void* stream) {
+                             int upsample2x, const void* zero_page, int flags, int dtype,
+                             void* workspace, size_t workspace_bytes, void* stream) {
   if (!zero_page) return PM_E_NULL;
   if (stride != 1 && stride != 2) return PM_E_SHAPE;
   if (upsample2x && stride != 1) return PM_E_SHAPE;
@@ -402,6 +522,9 @@ extern "C" int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const f
   p.Hin = (int)H; p.Win = (int)W; p.Hv = (int)Hv; p.Wv = (int)Wv; p.Cin = (int)Cin;
   p.Ho = (int)Ho; p.Wo = (int)Wo; p.stride = stride; p.ups = upsample2x ? 1 : 0;
   p.zero = zero_page;
+  plan_split(p, workspace, workspace_bytes);
+  if (!upsample2x && (Cin % BK) == 0)
+    PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_CONV3X3_FAST>(p, flags, (hipStream_t)stream)));
   PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_CONV3X3>(p, flags, (hipStream_t)stream)));
 }
 
@@ -409,9 +532,11 @@ extern "C" int pm_conv_temporal_k3(const void* x, int64_t ldx, const void* halo_
                                    const void* halo_hi, const void* Wp, const float* bias,
                                    const void* residual, int64_t ldr, void* y, int64_t ldy,
                                    int64_t F, int64_t P, int64_t Cin, int64_t Cout,
-                                   const void* zero_page, int flags, int dtype, void* stream) {
+                                   const void* zero_page, int flags, int dtype, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
   if (!zero_page) return PM_E_NULL;
   if ((Cin & 7) || (ldx & ((flags & PM_FLAG_A_F32) ? 3 : 7)) || ldx < Cin) return PM_E_SHAPE;
+  if (Cin % BK) return PM_E_SHAPE;  // one tap per K-tile
   const int64_t M = F * P, K = 3 * Cin;
   int rc = check_common(x, Wp, y, M, Cout, K, PM_ACT_NONE);
   if (rc) return rc;
@@ -422,5 +547,12 @@ extern "C" int pm_conv_temporal_k3(const void* x, int64_t ldx, const void* halo_
   p.ntiles = (int)((Cout + BN - 1) / BN);
   p.Cin = (int)Cin; p.F = (int)F; p.P = (int)P; p.halo_lo = halo_lo; p.halo_hi = halo_hi;
   p.zero = zero_page;
+  plan_split(p, workspace, workspace_bytes);
   PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_CONVT3>(p, flags, (hipStream_t)stream)));
+}
+
+extern "C" size_t pm_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int act) {
+  int ktps;
+  const int s = choose_splits(M, N, K, act, &ktps);
+  return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }

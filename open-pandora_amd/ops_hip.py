@@ -20,7 +20,7 @@ def _ptr(t):
 class HipOps:
     name = "hip"
 
-    def __init__(self, dtype=torch.bfloat16, device="cuda"):
+    def __init__(self, dtype=torch.bfloat16, device="cuda", workspace_mb=256):
         if dtype not in _DT:
             raise ValueError(f"HipOps supports float16/bfloat16 activations, got {dtype}")
         self.lib = capi.load()
@@ -30,6 +30,10 @@ class HipOps:
         if self.device.type != "cuda":
             raise capi.PandoraKernelError("HipOps needs a ROCm device (cuda:N)")
         self.zero_page = torch.zeros(256, dtype=torch.uint8, device=self.device)
+        # split-K scratch for the GEMM family (deep levels: few output tiles, long K); one buffer per
+        # op table is enough because every launch on the stream is ordered after the previous reduce
+        self.ws_bytes = int(workspace_mb) << 20
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.device) if self.ws_bytes else None
 
     # -- helpers ---------------------------------------------------------------------------------
     def _stream(self):
@@ -70,7 +74,7 @@ class HipOps:
         rc = self.lib.pm_gemm(_ptr(a), self._rows(a, True), _ptr(w), K, _ptr(bias),
                               _ptr(residual), residual.stride(0) if residual is not None else 0,
                               _ptr(out), out.stride(0), M, N, K, capi.ACT_CODES[act], flags, self.dt,
-                              self._stream())
+                              _ptr(self.workspace), self.ws_bytes, self._stream())
         capi.check(rc, f"pm_gemm M={M} N={N} K={K}")
         return out
 
@@ -85,7 +89,8 @@ class HipOps:
         rc = self.lib.pm_conv2d_3x3(_ptr(x), self._rows(x, True), _ptr(wp), _ptr(bias), _ptr(residual),
                                     residual.stride(0) if residual is not None else 0, _ptr(out),
                                     out.stride(0), F, H, W, cin, cout, stride, int(upsample),
-                                    _ptr(self.zero_page), flags, self.dt, self._stream())
+                                    _ptr(self.zero_page), flags, self.dt, _ptr(self.workspace),
+                                    self.ws_bytes, self._stream())
         capi.check(rc, f"pm_conv2d_3x3 F={F} H={H} W={W} Cin={cin} Cout={cout}")
         return out
 
@@ -101,7 +106,8 @@ class HipOps:
                                           _ptr(wp), _ptr(bias), _ptr(residual),
                                           residual.stride(0) if residual is not None else 0,
                                           _ptr(out), out.stride(0), F, P, cin, cout,
-                                          _ptr(self.zero_page), flags, self.dt, self._stream())
+                                          _ptr(self.zero_page), flags, self.dt, _ptr(self.workspace),
+                                    self.ws_bytes, self._stream())
         capi.check(rc, f"pm_conv_temporal_k3 F={F} P={P} Cin={cin} Cout={cout}")
         return out
 

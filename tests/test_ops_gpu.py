@@ -353,3 +353,39 @@ def test_ddim_update_f32_model_output(hip_ops_factory):
     assert rel_err(got_p, want_p) <= 1e-6
     y = rnd(F * P, C, dtype=torch.float32, seed=6)
     assert torch.equal(ops.unpack_output(y.cuda(), F, P).cpu(), REF.unpack_output(y, F, P))
+
+
+# ---- split-K (few output tiles, long K: the deep U-Net levels) ----------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_splitk_matches_unsplit_and_oracle(hip_ops_factory, dtype):
+    from open_pandora_amd import capi
+    from open_pandora_amd.ops_hip import HipOps
+    ops = hip_ops_factory(dtype)
+    nows = HipOps(dtype, "cuda:0", workspace_mb=0)  # NULL workspace => the same call runs unsplit
+    lib = capi.load()
+    # dense: M=640, N=1280, K=5120 (ff2 at the deepest level)
+    M, N, K = 640, 1280, 5120
+    assert lib.pm_gemm_workspace_bytes(M, N, K, 0) > 0
+    a, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=2)
+    bias, res32 = rnd(N, dtype=torch.float32, seed=3), rnd(M, N, dtype=torch.float32, seed=4)
+    want = REF.gemm(a, w, bias, res32)
+    got = ops.gemm(a.cuda(), w.cuda(), bias.cuda(), res32.cuda(), stream=True)
+    ref2 = nows.gemm(a.cuda(), w.cuda(), bias.cuda(), res32.cuda(), stream=True)
+    assert rel_err(got, want) <= 2e-5 and rel_err(got, ref2) <= 2e-6
+    got16 = ops.gemm(a.cuda(), w.cuda(), bias.cuda(), act="silu")
+    assert rel_err(got16, REF.gemm(a, w, bias, act="silu")) <= TOL[dtype]
+    # conv3x3 at the deepest level: 16 x 5 x 8 pixels, 1280 -> 1280 channels (K = 11520)
+    F, H, W, C = 16, 5, 8, 1280
+    assert lib.pm_gemm_workspace_bytes(F * H * W, C, 9 * C, 0) > 0
+    x = rnd(F * H * W, C, dtype=dtype, seed=5)
+    wp = rnd(C, 9 * C, dtype=dtype, scale=(9 * C) ** -0.5, seed=6)
+    b2 = rnd(C, dtype=torch.float32, seed=7)
+    want = REF.conv3x3(x, wp, b2, F, H, W)
+    got = ops.conv3x3(x.cuda(), wp.cuda(), b2.cuda(), F, H, W)
+    assert rel_err(got, want) <= TOL[dtype]
+    assert rel_err(got, nows.conv3x3(x.cuda(), wp.cuda(), b2.cuda(), F, H, W)) <= TOL[dtype]
+    # temporal conv, same level
+    wt = rnd(C, 3 * C, dtype=dtype, scale=(3 * C) ** -0.5, seed=8)
+    want = REF.conv_t3(x, wt, b2, F, H * W)
+    got = ops.conv_t3(x.cuda(), wt.cuda(), b2.cuda(), F, H * W)
+    assert rel_err(got, want) <= TOL[dtype]
