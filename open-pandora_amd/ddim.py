@@ -15,6 +15,8 @@ guidance_rescale, **kwargs)` -> (samples, intermediates), including the gradio p
 * noise comes from an injectable `noise_fn(step_index, shape) -> f32 tensor` (default: torch.randn
   on the device), so both sides of a parity run can consume the same draws.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -33,12 +35,41 @@ def make_ddim_timesteps(method, num_ddim, num_ddpm):
     raise NotImplementedError(f'There is no ddim discretization method called "{method}"')
 
 
+class _ForwardGraph:
+    """The U-Net forwards of one DDIM step (cond and, with CFG, uncond) captured once into a HIP graph
+    and replayed every step: ~2000 kernel launches per step become one graph launch.  Inputs live in
+    static buffers (latent, timestep); the condition tensors are read in place at replay."""
+
+    def __init__(self, model, x, t, c, uc, fs, kwargs):
+        self.x = x.clone()
+        self.t = t.clone()
+        dev = x.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # warm-up outside capture: packs weights, sizes the allocator
+            model.apply_model(self.x, self.t, c, fs=fs, **kwargs)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.e_c = model.apply_model(self.x, self.t, c, fs=fs, **kwargs)
+            self.e_u = model.apply_model(self.x, self.t, uc, fs=fs, **kwargs) if uc is not None else None
+
+    def __call__(self, x, t):
+        self.x.copy_(x)
+        self.t.copy_(t)
+        self.graph.replay()
+        return self.e_c, self.e_u
+
+
 class DDIMSampler:
-    def __init__(self, model, schedule="linear", **kwargs):
+    def __init__(self, model, schedule="linear", use_graph=None, **kwargs):
         self.model = model
         self.ddpm_num_timesteps = model.num_timesteps
         self.schedule = schedule
         self.counter = 0
+        # HIP-graph replay of the forwards (single-GPU HipOps only; PANDORA_HIPGRAPH=0 disables)
+        self.use_graph = (os.environ.get("PANDORA_HIPGRAPH", "1") != "0") if use_graph is None else use_graph
+        self._graphs = {}
 
     def _ops(self):
         ops = getattr(self.model, "ops", None)
@@ -123,8 +154,21 @@ class DDIMSampler:
         if step is None:
             step = int(t[0])  # device sync; ddim_sampling passes the host-side value instead
         use_cfg = unconditional_conditioning is not None and unconditional_guidance_scale != 1.0
-        e_c = self.model.apply_model(x, t, c, fs=fs, **kwargs)
-        e_u = self.model.apply_model(x, t, unconditional_conditioning, fs=fs, **kwargs) if use_cfg else None
+        uc = unconditional_conditioning if use_cfg else None
+        unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
+        graphable = (self.use_graph and getattr(ops, "supports_graphs", False) and isinstance(c, dict)
+                     and getattr(unet, "fp", None) is None and x.is_cuda)
+        if graphable:
+            tensors = [v for d in (c, uc or {}) for lst in d.values() for v in lst] + ([fs] if torch.is_tensor(fs) else [])
+            key = (tuple(x.shape), tuple((v.data_ptr(), tuple(v.shape)) for v in tensors), tuple(sorted(kwargs)))
+            g = self._graphs.get(key)
+            if g is None:
+                self._graphs.clear()  # one live graph: its private pool holds a forward's activations
+                g = self._graphs[key] = _ForwardGraph(self.model, x, t, c, uc, fs, kwargs)
+            e_c, e_u = g(x, t)
+        else:
+            e_c = self.model.apply_model(x, t, c, fs=fs, **kwargs)
+            e_u = self.model.apply_model(x, t, uc, fs=fs, **kwargs) if use_cfg else None
         sc = self.step_scalars(index, step)
         if sc["sigma"] != 0.0:
             if noise is None:

@@ -19,6 +19,7 @@ def _ptr(t):
 
 class HipOps:
     name = "hip"
+    supports_graphs = True  # every op only enqueues kernels on the current stream: capturable
 
     def __init__(self, dtype=torch.bfloat16, device="cuda", workspace_mb=256):
         if dtype not in _DT:

@@ -32,12 +32,18 @@ def _unsupported(flag, name):
         raise NotImplementedError(f"{name} is not used by the shipped Open-Pandora configs and is not built")
 
 
+_FREQS = {}
+
+
 def timestep_embedding(timesteps, dim, max_period=10000):
     """Sinusoidal embedding with the reference's bf16-quantised frequency table
     (utils_diffusion.py:8-28: `torch.arange(..., dtype=torch.bfloat16)` feeds the exp)."""
-    half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.bfloat16) / half)
-    args = timesteps[:, None].float() * freqs.to(timesteps.device)[None].float()
+    key = (dim, max_period, str(timesteps.device))
+    if key not in _FREQS:  # built on the host once per device (no H2D copy inside a graph capture)
+        half = dim // 2
+        freqs = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.bfloat16) / half)
+        _FREQS[key] = freqs.float().to(timesteps.device)
+    args = timesteps[:, None].float() * _FREQS[key][None]
     return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
 
 
@@ -343,6 +349,8 @@ class UNetModel(nn.Module):
             W["fps_embedding"] = [lin(self.fps_embedding[0]), lin(self.fps_embedding[2])]
         self._names = {m: n for n, m in self.named_modules()}
         self._packed = W
+        for t in ([0], [self.default_fs]):  # warm the frequency-table cache for this device
+            timestep_embedding(torch.tensor(t, device=dev), self.model_channels)
         return self
 
     # ---- graph ---------------------------------------------------------------------------------
