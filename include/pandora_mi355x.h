@@ -112,19 +112,20 @@ int pm_conv_temporal_k3(const void* x, int64_t ldx, const void* halo_lo, const v
  * attention.py:331,368).
  *   x: [NI, P, C] of in_dtype (PM_F16 / PM_BF16 / PM_F32): NI independent instances (NI = frames for per-frame statistics, NI = 1 with
  *   P = F*H*W for (T,H,W) statistics); C % 8 == 0, (C/8) <= 1024, C % groups == 0.
- *   pm_groupnorm_stats writes partial {sum, sum of squares} per (instance, chunk, group) into
- *   `partials` [NI, nchunks, groups, 2] f32; nchunks = pm_groupnorm_nchunks(P, C).
- *   pm_groupnorm_apply reduces `partials` over nchunks in a fixed order (deterministic), then
- *   y = (x - mean) * rstd * gamma + beta, optionally SiLU.  count = elements per group the
- *   statistics were taken over (P * C/groups, or the all-rank total in frame-sharded mode).
+ *   pm_groupnorm_stats: per-chunk partial {sum, sum of squares} go to the scratch `partials`
+ *   [NI, nchunks, groups, 2] f32 (nchunks = pm_groupnorm_nchunks(P, C)), then are summed in a fixed
+ *   order (deterministic, no atomics) into `totals` [NI, groups, 2] f32.
+ *   pm_groupnorm_apply: y = (x - mean) * rstd * gamma + beta, optionally SiLU, from `totals`;
+ *   count = elements per group the totals were taken over (P * C/groups, or the all-rank total in
+ *   frame-sharded mode, where the caller all-reduces `totals` between the two calls).
  */
 int64_t pm_groupnorm_nchunks(int64_t P, int64_t C);
-int pm_groupnorm_stats(const void* x, int64_t ldx, float* partials, int64_t NI, int64_t P,
-                       int64_t C, int groups, int in_dtype, void* stream);
-int pm_groupnorm_apply(const void* x, int64_t ldx, const float* partials, int64_t nchunks,
-                       const float* gamma, const float* beta, void* y, int64_t ldy, int64_t NI,
-                       int64_t P, int64_t C, int groups, double count, float eps, int silu,
-                       int in_dtype, int out_dtype, void* stream);
+int pm_groupnorm_stats(const void* x, int64_t ldx, float* partials, float* totals, int64_t NI,
+                       int64_t P, int64_t C, int groups, int in_dtype, void* stream);
+int pm_groupnorm_apply(const void* x, int64_t ldx, const float* totals, const float* gamma,
+                       const float* beta, void* y, int64_t ldy, int64_t NI, int64_t P, int64_t C,
+                       int groups, double count, float eps, int silu, int in_dtype, int out_dtype,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * pm_layernorm: LayerNorm over the last dimension; replaces BasicTransformerBlock.norm1/2/3

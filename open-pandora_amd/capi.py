@@ -29,9 +29,9 @@ SIGNATURES = {
                                     c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                     c_int64, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "pm_groupnorm_nchunks": (c_int64, [c_int64, c_int64]),
-    "pm_groupnorm_stats": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int,
-                                   c_int, c_void_p]),
-    "pm_groupnorm_apply": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+    "pm_groupnorm_stats": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                                   c_int, c_int, c_void_p]),
+    "pm_groupnorm_apply": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_double,
                                    c_float, c_int, c_int, c_int, c_void_p]),
     "pm_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,

@@ -32,6 +32,15 @@ constexpr int KV_TILE = 64;
 constexpr int KV_TILE_BYTES = KV_TILE * 128;  // 64 keys x 64 dims x 2 B
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+// value held by lane ^ 32 (v_permlane32_swap: no LDS round trip)
+__device__ __forceinline__ float other_half(float v) {
+  const unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
 
 template <typename T> __device__ __forceinline__ typename Vec<T>::v8 tr_pair(const char* base, int off0, int off1) {
   // two transposed 4x16 block reads -> 8 keys of one d column (the 32x32x16 A-operand fragment)
@@ -82,23 +91,22 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     const int64_t krs = p.k_rs[seg];
     const int nkt = (Nk + KV_TILE - 1) / KV_TILE;
 
-    u32x4 rk[2], rv[2];
-    auto load_kv = [&](int kt) {
+    // K/V tiles go global -> LDS by DMA (1 KiB per wave-instruction, lane-linear image); the XOR
+    // swizzles are applied on the source side: this lane fills physical slot tid & 7 of rows
+    // lr + 32 j with logical chunk  slot ^ ((row >> 1) & 7)  (K: conflict-free ds_read_b128 for the
+    // 32-row MFMA operand) resp.  slot ^ (((row >> 1) & 1) << 2)  (V: conflict-free transposed reads).
+    const int kc = (tid & 7) ^ ((lr >> 1) & 7);
+    const int vc = (tid & 7) ^ (((lr >> 1) & 1) << 2);
+    const T* kgl = kg + (kc - lc) * 8;
+    const T* vgl = vg + (vc - lc) * 8;
+    auto load_kv = [&](int kt, int buf) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         int key = kt * KV_TILE + lr + 32 * j;
         if (key > Nk - 1) key = Nk - 1;
-        rk[j] = ld_global16(kg + (int64_t)key * krs);
-        rv[j] = ld_global16(vg + (int64_t)key * krs);
-      }
-    };
-    auto store_kv = [&](int buf) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int row = lr + 32 * j;
-        *reinterpret_cast<u32x4*>(Ks + buf * KV_TILE_BYTES + row * 128 + ((lc ^ (row & 7)) << 4)) = rk[j];
-        *reinterpret_cast<u32x4*>(Vs + buf * KV_TILE_BYTES + row * 128 +
-                                  ((lc ^ (((row >> 1) & 1) << 2)) << 4)) = rv[j];
+        const int dst = buf * KV_TILE_BYTES + (32 * j + 8 * wave) * 128;
+        __builtin_amdgcn_global_load_lds((glb_void*)(kgl + (int64_t)key * krs), (lds_void*)(Ks + dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void*)(vgl + (int64_t)key * krs), (lds_void*)(Vs + dst), 16, 0, 0);
       }
     };
 
@@ -109,13 +117,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
       for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    load_kv(0);
-    store_kv(0);
-    __syncthreads();
+    load_kv(0, 0);
+    __syncthreads();  // drains the DMA (vmcnt) before the barrier
 
     for (int kt = 0; kt < nkt; ++kt) {
       const int buf = kt & 1;
-      if (kt + 1 < nkt) load_kv(kt + 1);
+      if (kt + 1 < nkt) load_kv(kt + 1, buf ^ 1);
       const char* ks = Ks + buf * KV_TILE_BYTES;
       const char* vs = Vs + buf * KV_TILE_BYTES;
 
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         for (int s = 0; s < 4; ++s) {
           Pack8<T> kf;
           const int chunk = 2 * s + hh;
-          kf.u = *reinterpret_cast<const u32x4*>(ks + row * 128 + ((chunk ^ (row & 7)) << 4));
+          kf.u = *reinterpret_cast<const u32x4*>(ks + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
           sacc[kb] = mfma32(kf.v, qf[s].v, sacc[kb]);
         }
       }
@@ -150,10 +157,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = fmaxf(mx, other_half(mx));
       const float m_new = fmaxf(m_run, mx * p.scale_log2e);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
+      // rescale only when some row's running max actually grew (alpha == 1 exactly otherwise)
+      if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+        m_run = m_new;
+      }
       float psum = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -163,11 +178,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
           sacc[kb][r] = pv;
           psum += pv;
         }
-      l_run = l_run * alpha + psum;
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+      l_run += psum;
 
       // ---- O^T += V^T . P^T ----
       const int trow = (lane & 15) >> 2;                 // row inside the 4x16 block
@@ -190,10 +201,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
           oacc[db] = mfma32(vf, pf.v, oacc[db]);
         }
       }
-      if (kt + 1 < nkt) store_kv(buf ^ 1);
       __syncthreads();
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = l_run + other_half(l_run);
     const float inv = p.w[seg] / l_tot;
 #pragma unroll
     for (int d = 0; d < 2; ++d)
@@ -217,9 +227,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Temporal self-attention: at every (pixel, head) a 16x16 (Fq x Fk) attention over the frame axis.
-// HBM-bound (0.1 % of the FLOPs): one thread per (pixel, head, query frame), f32 math in registers;
-// the Fq lanes of one (pixel, head) read the same K/V rows (served once from L1).
+// Temporal self-attention: at every (pixel, head) a (Fq x Fk <= 16 x 16) attention over the frame
+// axis, head dim 64.  HBM-bound (0.1 % of the FLOPs) - the job is to touch q, k, v, o once with wide
+// loads and keep the arithmetic off the VALU:
+//   one wave per (pixel, head) problem at a time, several problems per wave;
+//   S^T = K . Q^T   2 x v_mfma_f32_16x16x32: both operands are 16-byte row pieces loaded straight from
+//                   global memory in fragment order (lane = (frame, d-chunk)), no LDS;
+//   softmax over the 16 keys: 4 scores per lane + two cross-lane exchanges (lane ^ 16, lane ^ 32);
+//   O^T = V^T . P^T 4 x v_mfma_f32_16x16x16 (K = 16 keys, no padding): the S^T accumulator IS the P^T
+//                   operand (same lane map), V^T fragments come from a wave-private 2 KiB LDS image of
+//                   the [16 frames][64] V tile (filled by DMA) through ds_read_b64_tr_b16.
 struct TAttnParams {
   const void* q;
   const void* k;
@@ -227,79 +244,99 @@ struct TAttnParams {
   void* o;
   int64_t ldq, ldk, ldo;
   int Fq, Fk, P, heads;
-  float scale;
+  float scale_log2e;
+  int nprob;  // P * heads
 };
+
+__device__ __forceinline__ f32x4 mfma16k16(f16x4 a, f16x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16k16(bf16x4 a, bf16x4 b, f32x4 c) {
+  union { bf16x4 v; s16x4 s; } ua, ub;
+  ua.v = a;
+  ub.v = b;
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ua.s, ub.s, c, 0, 0, 0);
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void tattn_kernel(const TAttnParams p) {
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int fq = (int)(gid % p.Fq);
-  const int64_t ph = gid / p.Fq;
-  const int64_t total = (int64_t)p.P * p.heads;
-  if (ph >= total) return;
-  const int head = (int)(ph % p.heads);
-  const int64_t pix = ph / p.heads;
+  __shared__ __attribute__((aligned(16))) char smem[4 * 2048];  // one V image per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  char* const vimg = smem + wave * 2048;
+  const int fr = lane & 15, g = lane >> 4;  // fragment row (frame / d) and k-group
+  const int64_t qfs = (int64_t)p.P * p.ldq, kfs = (int64_t)p.P * p.ldk, ofs = (int64_t)p.P * p.ldo;
+  const T* Qg = reinterpret_cast<const T*>(p.q);
+  const T* Kg = reinterpret_cast<const T*>(p.k);
+  const T* Vg = reinterpret_cast<const T*>(p.v);
+  T* Og = reinterpret_cast<T*>(p.o);
+  const int fq_row = fr < p.Fq ? fr : p.Fq - 1;  // clamp: rows >= Fq are computed and dropped
+  const int fk_row = fr < p.Fk ? fr : p.Fk - 1;
+  // DMA of the V tile: instruction j fills keys 8j..8j+7 (lane i -> key 8j + i/8, physical 16-byte
+  // slot i%8); the slot is XOR-ed by ((key>>1)&3)<<1 on the SOURCE side (conflict-free tr reads)
+  const int dkey = lane >> 3, dslot = lane & 7;
+  // transposed-read addresses: lane i of a 16-lane group supplies row (key 4g + i/4), columns 4(i&3)..
+  const int tkey = 4 * g + (fr >> 2);
+  const int tsw = ((tkey >> 1) & 3) << 1;
 
-  const T* qp = reinterpret_cast<const T*>(p.q) + ((int64_t)fq * p.P + pix) * p.ldq + head * 64;
-  float qv[64];
+  const int waves_total = gridDim.x * 4;
+  for (int prob = blockIdx.x * 4 + wave; prob < p.nprob; prob += waves_total) {
+    const int pix = prob / p.heads, head = prob - pix * p.heads;
+    const T* qp = Qg + (int64_t)pix * p.ldq + head * 64;
+    const T* kp = Kg + (int64_t)pix * p.ldk + head * 64;
+    const T* vp = Vg + (int64_t)pix * p.ldk + head * 64;
+    // V tile -> LDS (2 x 1 KiB)
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    Pack8<T> t;
-    t.u = ld_global16(qp + 8 * c);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) qv[8 * c + e] = to_f32(t.e[e]) * p.scale;
-  }
-  float sc[16];
-  float mx = -INFINITY;
-  const T* kp = reinterpret_cast<const T*>(p.k) + pix * p.ldk + head * 64;
-  const T* vp = reinterpret_cast<const T*>(p.v) + pix * p.ldk + head * 64;
-  const int64_t fstride = (int64_t)p.P * p.ldk;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    if (j < p.Fk) {
-      float s = 0.f;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        Pack8<T> t;
-        t.u = ld_global16(kp + j * fstride + 8 * c);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s = fmaf(qv[8 * c + e], to_f32(t.e[e]), s);
-      }
-      sc[j] = s;
-      mx = fmaxf(mx, s);
+    for (int j = 0; j < 2; ++j) {
+      int key = 8 * j + dkey;
+      const int lslot = dslot ^ (((key >> 1) & 3) << 1);
+      if (key > p.Fk - 1) key = p.Fk - 1;
+      __builtin_amdgcn_global_load_lds((glb_void*)(vp + key * kfs + lslot * 8), (lds_void*)(vimg + j * 1024), 16, 0, 0);
     }
-  }
-  float l = 0.f;
+    // S^T = K . Q^T
+    f32x4 st = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int j = 0; j < 16; ++j)
-    if (j < p.Fk) {
-      sc[j] = __expf(sc[j] - mx);
-      l += sc[j];
+    for (int ks = 0; ks < 2; ++ks) {
+      Pack8<T> kf, qf;
+      kf.u = ld_global16(kp + fk_row * kfs + 32 * ks + 8 * g);
+      qf.u = ld_global16(qp + fq_row * qfs + 32 * ks + 8 * g);
+      st = mfma16(kf.v, qf.v, st);
     }
-  const float inv = 1.f / l;
-  float ov[64];
+    // st[r] = score(key = 4g + r, query = fr); softmax over keys in base 2
+    float sc[4], mx = -INFINITY;
 #pragma unroll
-  for (int e = 0; e < 64; ++e) ov[e] = 0.f;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    if (j < p.Fk) {
-      const float pj = sc[j] * inv;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        Pack8<T> t;
-        t.u = ld_global16(vp + j * fstride + 8 * c);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ov[8 * c + e] = fmaf(pj, to_f32(t.e[e]), ov[8 * c + e]);
-      }
+    for (int r = 0; r < 4; ++r) {
+      sc[r] = (4 * g + r < p.Fk) ? st[r] * p.scale_log2e : -INFINITY;
+      mx = fmaxf(mx, sc[r]);
     }
-  }
-  T* op = reinterpret_cast<T*>(p.o) + ((int64_t)fq * p.P + pix) * p.ldo + head * 64;
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float l = 0.f;
+    Pack4<T> pf;
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    Pack8<T> t;
+    for (int r = 0; r < 4; ++r) {
+      const float e = __builtin_amdgcn_exp2f(sc[r] - mx);
+      l += e;
+      pf.e[r] = from_f32<T>(e);
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = __builtin_amdgcn_rcpf(l);
+    // O^T = V^T . P^T
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the V image has landed (wave-private: no barrier)
+    T* op = Og + (int64_t)pix * p.ldo + head * 64 + fr * ofs;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) t.e[e] = from_f32<T>(ov[8 * c + e]);
-    st_global16(op + 8 * c, t.u);
+    for (int db = 0; db < 4; ++db) {
+      const int chunk = (2 * db + ((fr & 3) >> 1)) ^ tsw;
+      union { s16x4 s; typename Vec<T>::v4 v; } vf;
+      vf.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vimg + tkey * 128 + chunk * 16 + (fr & 1) * 8));
+      f32x4 ot = {0.f, 0.f, 0.f, 0.f};
+      ot = mfma16k16(vf.v, pf.v, ot);
+      // ot[r] = O[query fr][d = 16 db + 4g + r]
+      Pack4<T> ov;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ov.e[r] = from_f32<T>(ot[r] * inv);
+      if (fr < p.Fq) *reinterpret_cast<u32x2*>(op + 16 * db + 4 * g) = ov.u;
+    }
   }
 }
 
@@ -340,9 +377,13 @@ extern "C" int pm_attention_temporal(const void* q, int64_t ldq, const void* k, 
   if ((ldq | ldk | ldo) & 7) return PM_E_SHAPE;
   TAttnParams p{};
   p.q = q; p.k = k; p.v = v; p.o = o; p.ldq = ldq; p.ldk = ldk; p.ldo = ldo;
-  p.Fq = (int)Fq; p.Fk = (int)Fk; p.P = (int)P; p.heads = (int)heads; p.scale = scale;
-  const int64_t threads = P * heads * Fq;
-  dim3 grid((unsigned)((threads + 255) / 256));
+  p.Fq = (int)Fq; p.Fk = (int)Fk; p.P = (int)P; p.heads = (int)heads;
+  p.scale_log2e = scale * 1.4426950408889634f;
+  if (Fq > 16 || P * heads > (1ll << 30)) return PM_E_SHAPE;
+  p.nprob = (int)(P * heads);
+  int64_t nb = (p.nprob + 3) / 4;  // 4 waves per block; cap the grid and loop (8 waves/SIMD resident)
+  if (nb > 256 * 8) nb = 256 * 8;
+  dim3 grid((unsigned)nb);
   PM_DISPATCH_DTYPE(dtype, T,
                     hipLaunchKernelGGL((tattn_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, p);
                     return check_launch());

@@ -58,9 +58,21 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+// erf-GELU (attention.py:422, F.gelu default).  erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7,
+// f32-level): one v_exp, one v_rcp and 6 FMAs instead of libm's branchy erff - the GEGLU epilogue runs
+// it on every element of the widest GEMM output of each transformer block.
 __device__ __forceinline__ float gelu_erf_f(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float e = 1.0f - poly * t * __expf(-z * z);  // erf(|x| / sqrt 2)
+  return 0.5f * x + 0.5f * fabsf(x) * e;              // 0.5 x (1 + sign(x) erf(|x|/sqrt2))
 }
 
 __device__ __forceinline__ u32x4 ld_global16(const void* p) {

@@ -10,6 +10,7 @@
 // rounded on the way.  LDS rows are 128 B with the 16-byte chunk index XOR-ed by (row & 7) - applied
 // on the source side - so the ds_read_b128 fragment reads spread over the banks.  The epilogue goes through LDS
 // (f32) so that residual loads and output stores are full 16-byte row segments.
+#include <stdlib.h>
 #include <type_traits>
 #include "common.hpp"
 
@@ -57,13 +58,26 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
-template <typename T, int AMODE, bool A32>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+// BIG = false: 128x128 tile, 4 waves, 2 LDS stages, 2 workgroups per CU (any shape, split-K, f32 A).
+// BIG = true : 256x128 tile, 8 waves, 3 LDS stages of 48 KiB with the DMA of tile t+2 in flight across
+//              the barrier (counted s_waitcnt vmcnt + raw s_barrier): hides the global-load latency that
+//              bounds the 2-stage loop; used when the grid still fills the chip.
+template <typename T, int AMODE, bool A32, bool BIG>
+__global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const GemmParams p) {
+  static_assert(!(BIG && A32), "the big tile is DMA-only");
   typedef typename std::conditional<A32, float, T>::type TA;  // storage type of the A operand
   constexpr int ES = sizeof(TA);
+  constexpr int NT = BIG ? 512 : 256;        // threads
+  constexpr int WMW = BIG ? 4 : 2;           // waves along M (2 along N)
+  constexpr int BMT = WMW * 64;              // tile rows
+  constexpr int RSTEP = NT / 8;              // rows staged per loader pass
+  constexpr int BP = BN / RSTEP;             // loader passes over the W tile (A tile: always 4)
+  constexpr int A_BYTES = BMT * BK * 2, B_BYTES = BN * BK * 2;
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const As = smem;                    // [2][TILE_BYTES]
-  char* const Bs = smem + 2 * TILE_BYTES;   // [2][TILE_BYTES]
+  // stage s: A tile at s*STAGE_BYTES, W tile right behind it
+  char* const As = smem;
+  char* const Bs = smem + A_BYTES;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -75,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   const int split = wg0 % p.splits;
   const int wg = wg0 / p.splits;
   const int mt = wg / p.ntiles, nt = wg - mt * p.ntiles;
-  const int m0 = mt * BM, n0 = nt * BN;
+  const int m0 = mt * BMT, n0 = nt * BN;
   const int nk_all = (p.K + BK - 1) / BK;
   const int kt0 = split * p.ktps;
   const int kt1 = (kt0 + p.ktps < nk_all) ? kt0 + p.ktps : nk_all;
@@ -92,15 +106,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   // main loop spends SALU, not VALU, on them: the kernel is otherwise VALU-issue-bound next to the MFMAs.
   const int lr = tid >> 3;
   const int lc = (tid & 7) ^ (lr & 7);
-  uint32_t b_off[4], a_off[4];
+  uint32_t b_off[BP], a_off[4];
   int a_y[4], a_x[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int m = m0 + lr + 32 * j;
-    if (m > p.M - 1) m = p.M - 1;
-    int n = n0 + lr + 32 * j;
+  for (int j = 0; j < BP; ++j) {
+    int n = n0 + lr + RSTEP * j;
     if (n > p.N - 1) n = p.N - 1;
     b_off[j] = (uint32_t)(((int64_t)n * p.ldw + lc * 8) * 2);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int m = m0 + lr + RSTEP * j;
+    if (m > p.M - 1) m = p.M - 1;
     if (AMODE == A_DENSE) {
       a_off[j] = (uint32_t)(((int64_t)m * p.lda + lc * 8) * ES);
       a_y[j] = a_x[j] = 0;
@@ -135,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     ch_l = k_l - tap_l * p.Cin;
   }
 
-  u32x4 ra[4], ra_hi[4], rb[4];  // register staging (A32 only); ra_hi: second half of an f32 chunk
+  u32x4 ra[4], ra_hi[4], rb[BP];  // register staging (A32 only); ra_hi: second half of an f32 chunk
   // issue the loads of K-tile kt (tiles are requested in increasing order) into LDS buffer `buf`
   auto load_tile = [&](int kt, int buf) {
     const int kb = kt * BK;
@@ -180,14 +197,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         }
         src = ok ? Ab + a_off[j] + (((int64_t)iy * p.Win + ix) * p.lda + ch_l) * ES : zero;
       }
-      const char* wsrc = (AMODE == A_CONV3X3 && !kin_l) ? zero : wb + b_off[j];
       if constexpr (A32) {  // f32 stream operand: through registers (needs the f32 -> 16-bit rounding)
         ra[j] = ld_global16(src);
         ra_hi[j] = ld_global16(src + 16);
-        rb[j] = ld_global16(wsrc);
       } else {  // 16-bit operands: DMA straight into the tile, 1 KiB per wave-instruction
-        const int dst = buf * TILE_BYTES + (32 * j + 8 * wave) * 128;
+        const int dst = buf * STAGE_BYTES + (RSTEP * j + 8 * wave) * 128;
         __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(As + dst), 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BP; ++j) {
+      const char* wsrc = (AMODE == A_CONV3X3 && !kin_l) ? zero : wb + b_off[j];
+      if constexpr (A32) {
+        rb[j] = ld_global16(wsrc);
+      } else {
+        const int dst = buf * STAGE_BYTES + (RSTEP * j + 8 * wave) * 128;
         __builtin_amdgcn_global_load_lds((glb_void*)wsrc, (lds_void*)(Bs + dst), 16, 0, 0);
       }
     }
@@ -210,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     if constexpr (!A32) return;  // DMA path: the tile is already in flight to LDS
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int off = buf * TILE_BYTES + (lr + 32 * j) * 128 + ((tid & 7) << 4);
+      const int off = buf * STAGE_BYTES + (lr + RSTEP * j) * 128 + ((tid & 7) << 4);
       union { u32x4 u; float f[4]; } lo, hi;
       lo.u = ra[j];
       hi.u = ra_hi[j];
@@ -236,15 +260,32 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   const int a_frag = (wm * 64 + fr) * 128, b_frag = (wn * 64 + fr) * 128;
   const int slot0 = ((fq) ^ (fr & 7)) << 4, slot1 = ((4 + fq) ^ (fr & 7)) << 4;
 
-  load_tile(kt0, 0);
-  store_tile(0);
-  __syncthreads();  // (hipcc drains vmcnt before the barrier, so the DMA'd tile is visible)
+  int buf = 0;
+  if constexpr (BIG) {
+    load_tile(kt0, 0);
+    if (kt0 + 1 < kt1) load_tile(kt0 + 1, 1);
+  } else {
+    load_tile(kt0, 0);
+    store_tile(0);
+    __syncthreads();  // (hipcc drains vmcnt before the barrier, so the DMA'd tile is visible)
+  }
 
   for (int kt = kt0; kt < kt1; ++kt) {
-    const int buf = (kt - kt0) & 1;
-    if (kt + 1 < kt1) load_tile(kt + 1, buf ^ 1);
-    const char* as = As + buf * TILE_BYTES + a_frag;
-    const char* bs = Bs + buf * TILE_BYTES + b_frag;
+    if constexpr (BIG) {
+      // tile kt landed once at most the 6 DMAs of tile kt+1 are still outstanding (vmcnt counts in
+      // issue order); the barrier then (a) publishes every wave's part of tile kt and (b) proves that
+      // all waves finished reading stage (kt-1)%3, which the DMA of tile kt+2 issued below overwrites
+      if (kt + 1 < kt1)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 2 < kt1) load_tile(kt + 2, buf >= 1 ? buf - 1 : 2);
+    } else {
+      if (kt + 1 < kt1) load_tile(kt + 1, buf ^ 1);
+    }
+    const char* as = As + buf * STAGE_BYTES + a_frag;
+    const char* bs = Bs + buf * STAGE_BYTES + b_frag;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       Pack8<T> a[4], b[4];
@@ -258,9 +299,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(a[i].v, b[j].v, acc[i][j]);
     }
-    if (kt + 1 < kt1) store_tile(buf ^ 1);
-    __syncthreads();
+    if constexpr (BIG) {
+      buf = (buf == 2) ? 0 : buf + 1;
+    } else {
+      if (kt + 1 < kt1) store_tile(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
   }
+  if constexpr (BIG) __syncthreads();  // all fragment reads done before the stages become the epilogue scratch
 
   // ---------------- epilogue ----------------
   // split-K slices store raw f32 partials into their slab; bias/act/residual run in the reduce pass
@@ -308,10 +355,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   const bool out32 = partial || p.out32 != 0;
   const int64_t ldc = partial ? p.N : p.ldc;
   const int cpr = tw >> 3;         // 8-column chunks per row
-  const int rpp = 256 / cpr;       // rows per pass
+  const int rpp = NT / cpr;        // rows per pass
   const int scol = tid % cpr, srow = tid / cpr;
 
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < WMW; ++half) {
     if (wm == half) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -417,11 +464,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
   }
 }
 
+static bool g_allow_big = false;  // PANDORA_GEMM_BIG=1 enables the 256x128 tile (measured: no gain yet)
+static int g_split_min_nk = 24;     // PANDORA_SPLITK_MIN_NK: shortest K loop (in 64-wide tiles) that is split
+
 static int choose_splits(int64_t M, int64_t N, int64_t K, int act, int* ktps) {
   const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   const int nk = (int)((K + BK - 1) / BK);
   *ktps = nk;
-  if (act == PM_ACT_GEGLU || tiles >= 384 || nk < 8) return 1;
+  if (act == PM_ACT_GEGLU || tiles >= 384 || nk < g_split_min_nk) return 1;
   int64_t s = (512 + tiles - 1) / tiles;
   if (s > nk / 4) s = nk / 4;
   if (s > 32) s = 32;
@@ -431,6 +481,14 @@ static int choose_splits(int64_t M, int64_t N, int64_t K, int act, int* ktps) {
 }
 
 static void plan_split(GemmParams& p, void* workspace, size_t workspace_bytes) {
+  static const bool init = [] {
+    const char* e = getenv("PANDORA_GEMM_BIG");
+    g_allow_big = (e && e[0] == '1');
+    const char* m = getenv("PANDORA_SPLITK_MIN_NK");
+    if (m) g_split_min_nk = atoi(m);
+    return true;
+  }();
+  (void)init;
   int ktps;
   int s = choose_splits(p.M, p.N, p.K, p.act, &ktps);
   if (s > 1 && (workspace == nullptr || workspace_bytes < (size_t)s * p.M * p.N * sizeof(float))) {
@@ -442,16 +500,19 @@ static void plan_split(GemmParams& p, void* workspace, size_t workspace_bytes) {
   p.ws = reinterpret_cast<float*>(workspace);
 }
 
-template <typename T, int AMODE, bool A32> static int launch1(const GemmParams& p, hipStream_t stream) {
-  const int mtiles = (p.M + BM - 1) / BM;
+template <typename T, int AMODE, bool A32, bool BIG> static int launch1(const GemmParams& p, hipStream_t stream) {
+  constexpr int bm = BIG ? 256 : BM;
+  constexpr int nt = BIG ? 512 : 256;
+  constexpr int lds = BIG ? 3 * (256 + BN) * BK * 2 : 4 * TILE_BYTES;
+  const int mtiles = (p.M + bm - 1) / bm;
   const int grid = mtiles * p.ntiles * p.splits;
   static bool attr_set = false;  // idempotent; a benign race sets the same value twice
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, AMODE, A32>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, AMODE, A32, BIG>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<T, AMODE, A32>), dim3(grid), dim3(256), 4 * TILE_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm_kernel<T, AMODE, A32, BIG>), dim3(grid), dim3(nt), lds, stream, p);
   if (p.splits > 1) {
     const int64_t work = (int64_t)p.M * ((p.N + 3) / 4);
     int64_t nb = (work + 255) / 256;
@@ -462,7 +523,11 @@ template <typename T, int AMODE, bool A32> static int launch1(const GemmParams& 
 }
 
 template <typename T, int AMODE> static int launch(const GemmParams& p, int flags, hipStream_t stream) {
-  return (flags & PM_FLAG_A_F32) ? launch1<T, AMODE, true>(p, stream) : launch1<T, AMODE, false>(p, stream);
+  if (flags & PM_FLAG_A_F32) return launch1<T, AMODE, true, false>(p, stream);
+  // big tile when it still yields at least one workgroup per CU (and no split-K, no K tail)
+  const int64_t big_tiles = (int64_t)((p.M + 255) / 256) * p.ntiles;
+  if (AMODE != A_CONV3X3 && p.splits == 1 && big_tiles >= 256 && g_allow_big) return launch1<T, AMODE, false, true>(p, stream);
+  return launch1<T, AMODE, false, false>(p, stream);
 }
 
 static int check_common(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K,

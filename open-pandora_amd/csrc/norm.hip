@@ -6,7 +6,8 @@
 
 namespace pm {
 
-constexpr int GN_ROWS_PER_CHUNK = 64;  // many small chunks: the stats pass must fill 256 CUs
+// rows per statistics chunk: enough chunks to fill 256 CUs, few enough for a cheap second level
+__host__ __device__ inline int gn_rows_per_chunk(int64_t P) { return P <= 4096 ? 64 : 256; }
 
 // eight consecutive channels as f32, from a 16-bit or f32 row
 template <typename TI> __device__ __forceinline__ void load8(const TI* p, float (&v)[8]) {
@@ -42,8 +43,9 @@ __global__ void gn_stats_kernel(const TI* __restrict__ x, int64_t ldx, float* __
   const int k = blockDim.x / CV;
   const int cv = threadIdx.x % CV, rlane = threadIdx.x / CV;
   const int inst = blockIdx.y, chunk = blockIdx.x;
-  const int r0 = chunk * GN_ROWS_PER_CHUNK;
-  int r1 = r0 + GN_ROWS_PER_CHUNK;
+  const int rpc = gn_rows_per_chunk(P);
+  const int r0 = chunk * rpc;
+  int r1 = r0 + rpc;
   if (r1 > P) r1 = P;
   const TI* xp = x + ((int64_t)inst * P) * ldx + cv * 8;
   float s[8], ss[8];
@@ -82,11 +84,36 @@ __global__ void gn_stats_kernel(const TI* __restrict__ x, int64_t ldx, float* __
   }
 }
 
+// grid NI; block 256: sums the per-chunk partials of one instance in a fixed order (deterministic):
+// 256 threads = (2*groups values) x (256/(2*groups) chunk lanes); each lane walks its chunks in order,
+// then the lanes are added in order.  Output totals [NI][groups][2].
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ partials,
+                                                           float* __restrict__ totals, int nchunks,
+                                                           int groups) {
+  __shared__ float red[1024];
+  const int inst = blockIdx.x;
+  const int nv = 2 * groups;
+  const int lanes = 1024 / nv;
+  const int vidx = threadIdx.x % nv, ln = threadIdx.x / nv;
+  float a = 0.f;
+  if (ln < lanes) {
+    const float* pp = partials + (int64_t)inst * nchunks * nv + vidx;
+    for (int c = ln; c < nchunks; c += lanes) a += pp[(int64_t)c * nv];
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  if ((int)threadIdx.x < nv) {
+    float t = 0.f;
+    for (int j = 0; j < lanes; ++j) t += red[j * nv + threadIdx.x];
+    totals[(int64_t)inst * nv + threadIdx.x] = t;
+  }
+}
+
 // grid (nblocks, NI); block 256.  sh: scale[C], shift[C]
 template <typename TI, typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const TI* __restrict__ x, int64_t ldx,
-                                                       const float* __restrict__ partials,
-                                                       int nchunks, const float* __restrict__ gamma,
+                                                       const float* __restrict__ totals,
+                                                       const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
                                                        T* __restrict__ y, int64_t ldy, int P, int C,
                                                        int groups, float inv_count, float eps,
@@ -96,29 +123,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const TI* __restrict__ x,
   float* shift = sh + C;
   float* gstat = sh + 2 * C;  // mean, rstd per group
   const int inst = blockIdx.y;
-  // reduce the per-chunk partials: 256 threads = (groups*2 values) x (256/(2*groups) chunk lanes),
-  // each lane walks its chunks in order, then the lanes are summed in order (deterministic)
-  float* red = sh + 2 * C + 2 * groups;  // [lanes][2*groups]
-  {
-    const int nv = 2 * groups;
-    const int lanes = 256 / nv;
-    const int vidx = threadIdx.x % nv, ln = threadIdx.x / nv;
-    if (ln < lanes) {
-      const float* pp = partials + (int64_t)inst * nchunks * nv + vidx;
-      float a = 0.f;
-      for (int c = ln; c < nchunks; c += lanes) a += pp[(int64_t)c * nv];
-      red[ln * nv + vidx] = a;
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < nv) {
-      float a = 0.f;
-      for (int j = 0; j < lanes; ++j) a += red[j * nv + threadIdx.x];
-      red[threadIdx.x] = a;
-    }
-    __syncthreads();
-  }
   if ((int)threadIdx.x < groups) {
-    const float a = red[threadIdx.x * 2], b = red[threadIdx.x * 2 + 1];
+    const float a = totals[((int64_t)inst * groups + threadIdx.x) * 2];
+    const float b = totals[((int64_t)inst * groups + threadIdx.x) * 2 + 1];
     const float mean = a * inv_count;
     float var = b * inv_count - mean * mean;
     if (var < 0.f) var = 0.f;
@@ -217,7 +224,8 @@ using namespace pm;
 
 extern "C" int64_t pm_groupnorm_nchunks(int64_t P, int64_t C) {
   (void)C;
-  return (P + GN_ROWS_PER_CHUNK - 1) / GN_ROWS_PER_CHUNK;
+  const int rpc = gn_rows_per_chunk(P);
+  return (P + rpc - 1) / rpc;
 }
 
 static int gn_check(int64_t NI, int64_t P, int64_t C, int groups, int64_t ldx, int in_dtype) {
@@ -246,8 +254,8 @@ static int gn_check(int64_t NI, int64_t P, int64_t C, int groups, int64_t ldx, i
   } while (0)
 
 template <typename TI>
-static int launch_stats(const void* x, int64_t ldx, float* partials, int64_t NI, int64_t P, int64_t C,
-                        int groups, hipStream_t stream) {
+static int launch_stats(const void* x, int64_t ldx, float* partials, float* totals, int64_t NI, int64_t P,
+                        int64_t C, int groups, hipStream_t stream) {
   const int nchunks = (int)pm_groupnorm_nchunks(P, C);
   const int threads = gn_threads((int)(C >> 3));
   if (threads < 2 * groups) return PM_E_SHAPE;
@@ -256,37 +264,39 @@ static int launch_stats(const void* x, int64_t ldx, float* partials, int64_t NI,
   const size_t shmem = (size_t)k * 2 * C * sizeof(float);
   hipLaunchKernelGGL((gn_stats_kernel<TI>), grid, dim3(threads), shmem, stream, (const TI*)x, ldx,
                      partials, (int)P, (int)C, groups, nchunks);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)NI), dim3(1024), 0, stream, partials, totals, nchunks,
+                     groups);
   return check_launch();
 }
 
-extern "C" int pm_groupnorm_stats(const void* x, int64_t ldx, float* partials, int64_t NI, int64_t P,
-                                  int64_t C, int groups, int in_dtype, void* stream) {
-  if (!x || !partials) return PM_E_NULL;
+extern "C" int pm_groupnorm_stats(const void* x, int64_t ldx, float* partials, float* totals, int64_t NI,
+                                  int64_t P, int64_t C, int groups, int in_dtype, void* stream) {
+  if (!x || !partials || !totals) return PM_E_NULL;
   int rc = gn_check(NI, P, C, groups, ldx, in_dtype);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (in_dtype == PM_F32) return launch_stats<float>(x, ldx, partials, NI, P, C, groups, st);
-  PM_DISPATCH_DTYPE(in_dtype, T, return launch_stats<T>(x, ldx, partials, NI, P, C, groups, st));
+  if (in_dtype == PM_F32) return launch_stats<float>(x, ldx, partials, totals, NI, P, C, groups, st);
+  PM_DISPATCH_DTYPE(in_dtype, T, return launch_stats<T>(x, ldx, partials, totals, NI, P, C, groups, st));
 }
 
-extern "C" int pm_groupnorm_apply(const void* x, int64_t ldx, const float* partials, int64_t nchunks,
+extern "C" int pm_groupnorm_apply(const void* x, int64_t ldx, const float* totals,
                                   const float* gamma, const float* beta, void* y, int64_t ldy,
                                   int64_t NI, int64_t P, int64_t C, int groups, double count,
                                   float eps, int silu, int in_dtype, int out_dtype, void* stream) {
-  if (!x || !partials || !gamma || !beta || !y) return PM_E_NULL;
+  if (!x || !totals || !gamma || !beta || !y) return PM_E_NULL;
   int rc = gn_check(NI, P, C, groups, ldx, in_dtype);
   if (rc) return rc;
-  if ((ldy & 7) || ldy < C || nchunks < 1 || count <= 0) return PM_E_SHAPE;
+  if ((ldy & 7) || ldy < C || count <= 0) return PM_E_SHAPE;
   const int64_t vecs = P * (C >> 3);
   int64_t nb = (vecs + 256 * 4 - 1) / (256 * 4);  // ~4 vectors per thread
   const int64_t cap = (2048 + NI - 1) / NI;
   if (nb > cap) nb = cap;
   if (nb < 1) nb = 1;
   dim3 grid((unsigned)nb, (unsigned)NI);
-  const size_t shmem = (2 * C + 2 * groups + 256) * sizeof(float);
+  const size_t shmem = (2 * C + 2 * groups) * sizeof(float);
   PM_DISPATCH_IN_OUT(in_dtype, out_dtype, TI, TO,
                      hipLaunchKernelGGL((gn_apply_kernel<TI, TO>), grid, dim3(256), shmem,
-                                        (hipStream_t)stream, (const TI*)x, ldx, partials, (int)nchunks,
+                                        (hipStream_t)stream, (const TI*)x, ldx, totals,
                                         gamma, beta, (TO*)y, ldy, (int)P, (int)C, groups,
                                         (float)(1.0 / count), eps, silu);
                      return check_launch());

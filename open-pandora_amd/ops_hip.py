@@ -124,40 +124,42 @@ class HipOps:
 
     # -- normalisation ---------------------------------------------------------------------------
     def groupnorm_stats(self, x, NI, groups=32):
-        """partial {sum, sumsq}: f32 [NI, nchunks, groups, 2]."""
+        """{sum, sumsq} per (instance, group): f32 [NI, groups, 2] (deterministic two-level sum)."""
         M, C = x.shape
         P = M // NI
         assert P * NI == M
         nch = self.lib.pm_groupnorm_nchunks(P, C)
         part = torch.empty(NI, nch, groups, 2, dtype=torch.float32, device=self.device)
-        rc = self.lib.pm_groupnorm_stats(_ptr(x), self._rows(x, True), _ptr(part), NI, P, C, groups,
-                                         self._in_dt(x), self._stream())
+        tot = torch.empty(NI, groups, 2, dtype=torch.float32, device=self.device)
+        rc = self.lib.pm_groupnorm_stats(_ptr(x), self._rows(x, True), _ptr(part), _ptr(tot), NI, P, C,
+                                         groups, self._in_dt(x), self._stream())
         capi.check(rc, f"pm_groupnorm_stats NI={NI} P={P} C={C}")
-        return part
+        return tot
 
-    def groupnorm_apply(self, x, partials, gamma, beta, eps, NI, silu, count=None, groups=32, out=None):
+    def groupnorm_apply(self, x, totals, gamma, beta, eps, NI, silu, count=None, groups=32, out=None):
         M, C = x.shape
         P = M // NI
         if count is None:
             count = float(P * (C // groups))
         if out is None:
             out = self.empty(M, C)
-        rc = self.lib.pm_groupnorm_apply(_ptr(x), self._rows(x, True), _ptr(partials), partials.shape[1],
-                                         _ptr(gamma), _ptr(beta), _ptr(out), self._rows(out), NI, P,
-                                         C, groups, float(count), float(eps), int(silu),
-                                         self._in_dt(x), self.dt, self._stream())
+        assert totals.shape == (NI, groups, 2) and totals.is_contiguous()
+        rc = self.lib.pm_groupnorm_apply(_ptr(x), self._rows(x, True), _ptr(totals), _ptr(gamma),
+                                         _ptr(beta), _ptr(out), self._rows(out), NI, P, C, groups,
+                                         float(count), float(eps), int(silu), self._in_dt(x), self.dt,
+                                         self._stream())
         capi.check(rc, f"pm_groupnorm_apply NI={NI} P={P} C={C}")
         return out
 
     def groupnorm(self, x, gamma, beta, eps, NI, silu, groups=32, stats_reduce=None, out=None):
-        """GroupNorm over NI instances of [P, C]; stats_reduce(partial [NI, groups, 2], local_count)
+        """GroupNorm over NI instances of [P, C]; stats_reduce(totals [NI, groups, 2], local_count)
         (frame-sharded mode) returns the all-rank totals and the total element count per group."""
-        part = self.groupnorm_stats(x, NI, groups)
+        tot = self.groupnorm_stats(x, NI, groups)
         count = None
         if stats_reduce is not None:
-            tot, count = stats_reduce(part.sum(dim=1), (x.shape[0] // NI) * (x.shape[1] // groups))
-            part = tot.reshape(NI, 1, groups, 2).contiguous()
-        return self.groupnorm_apply(x, part, gamma, beta, eps, NI, silu, count, groups, out)
+            tot, count = stats_reduce(tot, (x.shape[0] // NI) * (x.shape[1] // groups))
+            tot = tot.contiguous()
+        return self.groupnorm_apply(x, tot, gamma, beta, eps, NI, silu, count, groups, out)
 
     def layernorm(self, x, gamma, beta, eps=1e-5, out=None):
         M, C = x.shape

@@ -168,8 +168,8 @@ def test_groupnorm_external_stats(hip_ops_factory, dtype):
     beta = 0.3 * rnd(C, dtype=torch.float32, seed=3)
     want = REF.groupnorm(x, gamma, beta, 1e-5, 1, True)
     xs = [x[:P].cuda(), x[P:].cuda()]
-    parts = [ops.groupnorm_stats(t, 1).sum(dim=1) for t in xs]
-    total = (parts[0] + parts[1]).reshape(1, 1, 32, 2).contiguous()
+    parts = [ops.groupnorm_stats(t, 1) for t in xs]
+    total = (parts[0] + parts[1]).contiguous()
     count = 2 * P * (C // 32)
     got = torch.cat([ops.groupnorm_apply(t, total, gamma.cuda(), beta.cuda(), 1e-5, 1, True, count)
                      for t in xs], 0)
@@ -389,3 +389,41 @@ def test_splitk_matches_unsplit_and_oracle(hip_ops_factory, dtype):
     want = REF.conv_t3(x, wt, b2, F, H * W)
     got = ops.conv_t3(x.cuda(), wt.cuda(), b2.cuda(), F, H * W)
     assert rel_err(got, want) <= TOL[dtype]
+
+
+# ---- 256x128 big-tile path (3-stage DMA pipeline): needs >= 256 big tiles, i.e. large M ----------
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_large_m_gemm_conv_tconv(hip_ops_factory, dtype):
+    """Full-size M (40960 rows).  Also the shapes that take the optional 256x128 3-stage tile
+    (PANDORA_GEMM_BIG=1, run by tools/ab_gemm.sh; off by default: measured no faster)."""
+    ops = hip_ops_factory(dtype)
+    # dense: M = 40960 (+ ragged tail), N = 320 (2.5 column tiles), K = 320 and 1280, every epilogue
+    M = 40960 + 77
+    for K, N, act in ((320, 320, "none"), (1280, 320, "silu"), (320, 2560, "geglu")):
+        a = rnd(M, K, dtype=dtype, seed=1)
+        w = rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=2)
+        bias = rnd(N, dtype=torch.float32, seed=3)
+        res = None if act == "geglu" else rnd(M, N, dtype=torch.float32, seed=4)
+        want = REF.gemm(a, w, bias, res, act)
+        got = ops.gemm(a.cuda(), w.cuda(), bias.cuda(), None if res is None else res.cuda(), act,
+                       stream=res is not None)
+        tol = 2e-5 if res is not None and act == "none" else TOL[dtype]
+        assert rel_err(got, want) <= max(tol, 2e-5), (K, N, act, rel_err(got, want))
+    # exact-integer check through the big tile (fragment/stage bookkeeping)
+    g = torch.Generator().manual_seed(3)
+    a = torch.randint(-2, 3, (33000, 192), generator=g).to(dtype)
+    w = torch.randint(-2, 3, (256, 192), generator=g).to(dtype)
+    assert torch.equal(ops.gemm(a.cuda(), w.cuda()).float().cpu(), (a.float() @ w.float().t()).to(dtype).float())
+    # conv3x3 16 x 40 x 64, 64 -> 256 channels (padding, frame borders inside 256-row tiles)
+    F, H, W, Cin, Cout = 16, 40, 64, 64, 256
+    x = rnd(F * H * W, Cin, dtype=dtype, seed=5)
+    wp = rnd(Cout, 9 * Cin, dtype=dtype, scale=(9 * Cin) ** -0.5, seed=6)
+    b2 = rnd(Cout, dtype=torch.float32, seed=7)
+    assert rel_err(ops.conv3x3(x.cuda(), wp.cuda(), b2.cuda(), F, H, W), REF.conv3x3(x, wp, b2, F, H, W)) <= TOL[dtype]
+    want = REF.conv3x3(x, wp, b2, F, H, W, stride=2)
+    assert want.shape[0] == 16 * 20 * 32
+    # temporal conv 16 frames x 2560 pixels, 320 channels
+    xt = rnd(16 * 2560, 320, dtype=dtype, seed=8)
+    wt = rnd(320, 3 * 320, dtype=dtype, scale=960 ** -0.5, seed=9)
+    b3 = rnd(320, dtype=torch.float32, seed=10)
+    assert rel_err(ops.conv_t3(xt.cuda(), wt.cuda(), b3.cuda(), 16, 2560), REF.conv_t3(xt, wt, b3, 16, 2560)) <= TOL[dtype]
