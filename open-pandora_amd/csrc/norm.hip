@@ -7,7 +7,9 @@
 namespace pm {
 
 // rows per statistics chunk: enough chunks to fill 256 CUs, few enough for a cheap second level
-__host__ __device__ inline int gn_rows_per_chunk(int64_t P) { return P <= 4096 ? 64 : 256; }
+__host__ __device__ inline int gn_rows_per_chunk(int64_t P) {
+  return P <= 1024 ? 16 : (P <= 16384 ? 32 : (P <= 65536 ? 64 : 256));
+}
 
 // eight consecutive channels as f32, from a 16-bit or f32 row
 template <typename TI> __device__ __forceinline__ void load8(const TI* p, float (&v)[8]) {

@@ -1,0 +1,102 @@
+"""Caller surfaces of the hot path, with the names / arguments / return layout of the reference's
+world-model driver (model.py), restated around the MI355X path:
+
+  image_guided_synthesis(...)   model.py:703-781   condition assembly, n_samples loop, sampler call
+  get_latent_z(...)             model.py:690-701   conditioning-frame tiling to 16 latent frames
+  DiffusionRunner.generate(...) model.py:783-816   noise_shape from the conditioning frames
+  multi-round stitching         model.py:1094-1129, 1199-1211
+
+What is NOT here (out of scope for this tier): the ChatUniVi LLM + QFormer that produce
+`diffusion_conditioning`, the OpenCLIP image tower + Resampler that produce the image tokens, and the
+AutoencoderKL.  They enter as callables / tensors: `embed_image(img) -> (1, 256, 1024)` tokens,
+`uncond_text -> (1, 77, 1024)`, `encode_first_stage`, `decode_first_stage`; with `decode_first_stage=None`
+the latents are returned (that is what bench.py and the parity tests consume).
+"""
+import torch
+from einops import repeat
+
+from .ddim import DDIMSampler
+
+
+def get_latent_z(encode_first_stage, videos):
+    """videos (b, c, t, h, w) pixels -> (b, 4, 16, h/8, w/8): 1 frame is tiled x16, 4 frames x4
+    (model.py:690-701, the second - effective - definition)."""
+    b, c, t, h, w = videos.shape
+    z = encode_first_stage(videos.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w))
+    z = z.reshape(b, t, *z.shape[1:]).permute(0, 2, 1, 3, 4)
+    if t == 1:
+        z = repeat(z, "b c t h w -> b c (repeat t) h w", repeat=4)
+    return repeat(z, "b c t h w -> b c (repeat t) h w", repeat=4)
+
+
+@torch.no_grad()
+def image_guided_synthesis(diffusion_model, diffusion_conditioning, img_emb, uc_text_emb, uc_img_emb, z_cond,
+                           noise_shape, n_samples=1, ddim_steps=50, ddim_eta=1.0,
+                           unconditional_guidance_scale=1.0, cfg_img=None, fs=None, multiple_cond_cfg=False,
+                           timestep_spacing="uniform", guidance_rescale=0.0, decode_first_stage=None,
+                           sampler=None, **kwargs):
+    """model.py:703-781 with the encoders factored out.  Returns (batch, n_samples, c, t, h, w):
+    decoded frames if `decode_first_stage` is given, else latents."""
+    if multiple_cond_cfg:
+        raise NotImplementedError("DDIMSampler_multicond (SURVEY §8f row 4) is not built yet")
+    sampler = sampler or DDIMSampler(diffusion_model)
+    batch_size = noise_shape[0]
+    dev = z_cond.device
+    fs = torch.tensor([fs] * batch_size, dtype=torch.long, device=dev)
+    cond = {"c_crossattn": [torch.cat([diffusion_conditioning, img_emb], dim=1)], "c_concat": [z_cond]}
+    uc = None
+    if unconditional_guidance_scale != 1.0:
+        uc = {"c_crossattn": [torch.cat([uc_text_emb, uc_img_emb], dim=1)], "c_concat": [z_cond]}
+    kwargs.update({"unconditional_conditioning_img_nonetext": None})
+    variants = []
+    for _ in range(n_samples):  # independent replicas (model.py:749)
+        samples, _ = sampler.sample(S=ddim_steps, conditioning=cond, batch_size=batch_size, shape=noise_shape[1:],
+                                    verbose=kwargs.pop("verbose", False),
+                                    unconditional_guidance_scale=unconditional_guidance_scale,
+                                    unconditional_conditioning=uc, eta=ddim_eta, cfg_img=cfg_img, mask=None, x0=None,
+                                    fs=fs, timestep_spacing=timestep_spacing, guidance_rescale=guidance_rescale,
+                                    precision=diffusion_conditioning.dtype, **kwargs)
+        variants.append(decode_first_stage(samples) if decode_first_stage is not None else samples)
+    return torch.stack(variants).permute(1, 0, 2, 3, 4, 5)
+
+
+class DiffusionRunner:
+    """The part of WorldModel.generate / ChatWM that drives the denoiser (model.py:783-816, 989-1129)."""
+
+    GENERATE_KWARGS = {"unconditional_guidance_scale": 4, "ddim_steps": 50, "ddim_eta": 1.0, "fs": 15,
+                       "timestep_spacing": "uniform_trailing", "n_samples": 4}  # model.py:989-996
+
+    def __init__(self, diffusion_model, embed_image, uncond_text_emb, encode_first_stage, decode_first_stage=None):
+        self.diffusion_model = diffusion_model
+        self.embed_image = embed_image
+        self.uncond_text_emb = uncond_text_emb
+        self.encode_first_stage = encode_first_stage
+        self.decode_first_stage = decode_first_stage
+        self.sampler = DDIMSampler(diffusion_model)
+
+    @torch.no_grad()
+    def generate(self, diffusion_conditioning, diffusion_pixel_values, diffusion_cond_image, **generate_kwargs):
+        """diffusion_conditioning (1, 77, 1024) from the LLM side; diffusion_pixel_values (3, 1|4, H, W)
+        conditioning frames; diffusion_cond_image (1, 3, H, W).  -> (1, n_samples, c, 16, h, w)."""
+        kw = dict(self.GENERATE_KWARGS)
+        kw.update(generate_kwargs)
+        h, w = diffusion_pixel_values.shape[-2:]
+        z = get_latent_z(self.encode_first_stage, diffusion_pixel_values[None, ...])
+        img_emb = self.embed_image(diffusion_cond_image)
+        uc_img_emb = self.embed_image(torch.zeros_like(diffusion_cond_image))
+        T = self.diffusion_model.temporal_length
+        return image_guided_synthesis(self.diffusion_model, diffusion_conditioning[-1:], img_emb, self.uncond_text_emb,
+                                      uc_img_emb, z, [1, 4, T, h // 8, w // 8], sampler=self.sampler,
+                                      decode_first_stage=self.decode_first_stage, **kw)
+
+    @staticmethod
+    def stitch_rounds(videos):
+        """process_generated_video_multi (model.py:1199-1211): every round keeps frames 0-11, the last
+        all 16 -> 5 rounds = 64 frames."""
+        parts = [v[:, :, :, :12] for v in videos[:-1]] + [videos[-1]]
+        return torch.cat(parts, dim=3)
+
+    @staticmethod
+    def next_round_condition(frames):
+        """model.py:1120: the last 4 generated frames become the next round's conditioning frames."""
+        return frames[:, :, -4:]
