@@ -79,11 +79,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    local_rank %= max(1, torch.cuda.device_count())  # (a 1-GPU box can rehearse N ranks over gloo)
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        backend = os.environ.get("PANDORA_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
 
     from open_pandora_amd import factory, synth
     from open_pandora_amd.ddim import DDIMSampler
@@ -94,13 +99,19 @@ def main():
     pm = factory.build_diffusion(a.res, ops)
     h, w = factory.RESOLUTIONS[a.res]["image_size"]
     T = 16
-    fp = None
+    fp = cfgp = None
     mode = "1 GPU"
     if world > 1:
-        from open_pandora_amd.frame_parallel import FrameParallel
-        fp = FrameParallel(T, ops)
+        from open_pandora_amd.frame_parallel import make_hybrid
+        fp, cfgp = make_hybrid(T)
         pm.model.diffusion_model.bind(ops, fp)
-        mode = f"frames sharded {world}-way ({T // world}/GPU), RCCL all-gather/all-reduce"
+        fw = 1 if fp is None else fp.world
+        mode = (f"{'cond/uncond branch pair x ' if cfgp is not None else ''}{fw}-way frame shards "
+                f"({T // fw} frames/GPU), RCCL: 1 output exchange/step"
+                + ("" if fp is None else " + (T,H,W)-GN all-reduce, temporal-conv halo P2P, temporal K/V all-gather"))
+        # both partners of a CFG pair must draw the same DDIM noise for their (shared) frame shard
+        torch.manual_seed(1234 + (0 if fp is None else fp.rank))
+        torch.cuda.manual_seed(1234 + (0 if fp is None else fp.rank))
     ins = synth.synth_inputs(h, w, T, seed=123)
     cond = {"c_crossattn": [ins["c_crossattn"].to(dev)], "c_concat": [ins["c_concat"].to(dev)]}
     uc = {"c_crossattn": [ins["uc_crossattn"].to(dev)], "c_concat": [ins["c_concat"].to(dev)]}
@@ -111,7 +122,7 @@ def main():
         x = fp.shard_frames(x)
     fs = torch.tensor([15], device=dev)
     S = 50
-    smp = DDIMSampler(pm)
+    smp = DDIMSampler(pm, cfg_parallel=cfgp)
     smp.make_schedule(S, "uniform_trailing", 1.0, verbose=False)
     order = list(reversed(range(S)))  # index of the i-th loop iteration
 

@@ -62,8 +62,9 @@ class _ForwardGraph:
 
 
 class DDIMSampler:
-    def __init__(self, model, schedule="linear", use_graph=None, **kwargs):
+    def __init__(self, model, schedule="linear", use_graph=None, cfg_parallel=None, **kwargs):
         self.model = model
+        self.cfg_parallel = cfg_parallel  # frame_parallel.CFGParallel: this rank runs ONE CFG branch
         self.ddpm_num_timesteps = model.num_timesteps
         self.schedule = schedule
         self.counter = 0
@@ -157,7 +158,7 @@ class DDIMSampler:
         uc = unconditional_conditioning if use_cfg else None
         unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
         graphable = (self.use_graph and getattr(ops, "supports_graphs", False) and isinstance(c, dict)
-                     and getattr(unet, "fp", None) is None and x.is_cuda)
+                     and getattr(unet, "fp", None) is None and self.cfg_parallel is None and x.is_cuda)
         if graphable:
             tensors = [v for d in (c, uc or {}) for lst in d.values() for v in lst] + ([fs] if torch.is_tensor(fs) else [])
             key = (tuple(x.shape), tuple((v.data_ptr(), tuple(v.shape)) for v in tensors), tuple(sorted(kwargs)))
@@ -166,6 +167,9 @@ class DDIMSampler:
                 self._graphs.clear()  # one live graph: its private pool holds a forward's activations
                 g = self._graphs[key] = _ForwardGraph(self.model, x, t, c, uc, fs, kwargs)
             e_c, e_u = g(x, t)
+        elif self.cfg_parallel is not None and use_cfg:
+            mine = c if self.cfg_parallel.branch == 0 else uc
+            e_c, e_u = self.cfg_parallel.exchange(self.model.apply_model(x, t, mine, fs=fs, **kwargs))
         else:
             e_c = self.model.apply_model(x, t, c, fs=fs, **kwargs)
             e_u = self.model.apply_model(x, t, uc, fs=fs, **kwargs) if use_cfg else None

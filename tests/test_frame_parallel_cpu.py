@@ -15,7 +15,7 @@ from oracle.ops_torch import TorchOps
 from open_pandora_amd import synth
 from open_pandora_amd.ddim import DDIMSampler
 from open_pandora_amd.ddpm import LatentVisualDiffusion
-from open_pandora_amd.frame_parallel import FrameParallel
+from open_pandora_amd.frame_parallel import FrameParallel, make_hybrid
 from open_pandora_amd.unet import UNetModel
 from test_oracle_golden import RH_KW
 
@@ -34,14 +34,14 @@ def _build(fp=None):
     return LatentVisualDiffusion(m)
 
 
-def _sample(pm, fp, S, eta):
+def _sample(pm, fp, S, eta, cfgp=None):
     ins, cond, uc = gr.sampler_inputs(8, 8)
     ns = gr.noises(ins["x_T"].shape, S)
     sh = (lambda t: t) if fp is None else fp.shard_frames
     cond = {"c_crossattn": cond["c_crossattn"], "c_concat": [sh(cond["c_concat"][0])]}
     uc = {"c_crossattn": uc["c_crossattn"], "c_concat": [sh(uc["c_concat"][0])]}
     F = 16 if fp is None else fp.local_frames
-    y, _ = DDIMSampler(pm).sample(S=S, batch_size=1, shape=(4, F, 8, 8), conditioning=cond, verbose=False,
+    y, _ = DDIMSampler(pm, cfg_parallel=cfgp).sample(S=S, batch_size=1, shape=(4, F, 8, 8), conditioning=cond, verbose=False,
                                   unconditional_guidance_scale=4.0, unconditional_conditioning=uc, eta=eta,
                                   fs=torch.tensor([15]), timestep_spacing="uniform_trailing", x_T=sh(ins["x_T"]),
                                   noise_fn=lambda i, shape: sh(ns[i]))
@@ -71,3 +71,34 @@ def test_frame_sharded_sampling_matches_single_process(tmp_path, world, S, eta):
     assert err < 2e-5, err
     # 2 forwards/step: 105 (T,H,W) GroupNorms, 88 temporal convs, 34 temporal attentions each
     assert got["calls"] == {"reduce_stats": 105 * 2 * S, "exchange_halo": 88 * 2 * S, "gather_kv": 34 * 2 * S}
+
+
+def _hybrid_worker(rank, world, port, S, eta, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fp, cfgp = make_hybrid(16)
+        pm = _build(fp)
+        y = _sample(pm, fp, S, eta, cfgp)
+        if fp is not None:
+            y = fp.gather_frames(y)
+        torch.save({"y": y, "fp_calls": None if fp is None else fp.calls, "cfg_calls": cfgp.calls}, f"{out}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,S,eta", [(2, 3, 1.0), (4, 2, 0.0)])
+def test_cfg_pair_plus_frame_sharding_matches_single_process(tmp_path, world, S, eta):
+    """world 2: cond / uncond on two ranks, no in-forward collectives; world 4: 2 CFG branches x 2 frame
+    shards.  Every rank ends with the same latent as the single-process run."""
+    out = str(tmp_path / "y.pt")
+    mp.spawn(_hybrid_worker, args=(world, _free_port(), S, eta, out), nprocs=world, join=True)
+    want = _sample(_build(None), None, S, eta)
+    for r in range(world):
+        got = torch.load(f"{out}.{r}")
+        assert ((got["y"] - want).norm() / want.norm()).item() < 2e-5, r
+        assert got["cfg_calls"] == S
+        if world == 2:
+            assert got["fp_calls"] is None
+        else:  # ONE forward per step and rank
+            assert got["fp_calls"] == {"reduce_stats": 105 * S, "exchange_halo": 88 * S, "gather_kv": 34 * S}
