@@ -18,6 +18,13 @@ import torch
 import torch.distributed as dist
 
 
+def _host_staged_sync(t, group=None):
+    """gloo (the CPU-test / single-GPU rehearsal backend) stages CUDA tensors through the host without
+    ordering against the producing stream; RCCL ("nccl") is stream-ordered and needs nothing."""
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        torch.cuda.current_stream(t.device).synchronize()
+
+
 class FrameParallel:
     def __init__(self, total_frames, ops=None, group=None):
         assert dist.is_initialized(), "init_process_group first (one process per GPU)"
@@ -41,6 +48,7 @@ class FrameParallel:
     def gather_frames(self, x_local, dim=2):
         """inverse of shard_frames: every rank receives the whole clip."""
         parts = [torch.empty_like(x_local) for _ in range(self.world)]
+        _host_staged_sync(x_local, self.group)
         dist.all_gather(parts, x_local.contiguous(), group=self.group)
         return torch.cat(parts, dim=dim)
 
@@ -49,6 +57,7 @@ class FrameParallel:
         """partial f32 [NI, groups, 2] local {sum, sumsq} -> (all-rank totals, total element count)."""
         self.calls["reduce_stats"] += 1
         tot = partial.contiguous().clone()
+        _host_staged_sync(tot, self.group)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
         return tot, float(local_count) * self.world
 
@@ -57,6 +66,7 @@ class FrameParallel:
         self.calls["exchange_halo"] += 1
         first = t[:P].contiguous()
         last = t[(self.local_frames - 1) * P:].contiguous()
+        _host_staged_sync(t, self.group)
         lo = torch.empty_like(first) if self.rank > 0 else None
         hi = torch.empty_like(first) if self.rank < self.world - 1 else None
         ops = []
@@ -74,6 +84,7 @@ class FrameParallel:
         """qkv [F_local, P, 3*inner] (q|k|v): returns k, v views [T, P, inner] over all frames."""
         self.calls["gather_kv"] += 1
         kv_local = qkv[..., inner:].contiguous()
+        _host_staged_sync(kv_local, self.group)
         kv_all = torch.empty((self.total_frames,) + tuple(kv_local.shape[1:]), dtype=kv_local.dtype,
                              device=kv_local.device)
         if self.backend == "gloo":
@@ -100,6 +111,7 @@ class CFGParallel:
         self.calls += 1
         e_mine = e_mine.contiguous()
         e_other = torch.empty_like(e_mine)
+        _host_staged_sync(e_mine)
         ops = [dist.P2POp(dist.isend, e_mine, self.partner), dist.P2POp(dist.irecv, e_other, self.partner)]
         for req in dist.batch_isend_irecv(ops):
             req.wait()
