@@ -163,6 +163,11 @@ def main():
 
     if rank == 0:
         ms, n, fl = ops.summary()
+        traffic = None  # per-launch HBM-side bytes of the dominant kernel, from the committed PMC passes
+        tj = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+        if a.res == "320x512" and os.path.exists(tj):
+            with open(tj) as f:
+                traffic = json.load(f)["conv3x3"]["traffic_bytes"]
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         out = {
             "metric": "denoising_steps_per_sec", "value": a.steps / elapsed, "unit": "steps/s",
@@ -176,7 +181,7 @@ def main():
             "whole_step_mfma_frac": FLOP_PER_STEP[a.res] / (elapsed / a.steps) / 1e12 / MFMA_PEAK_TFLOPS / world,
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel<A_CONV3X3> (pm_conv2d_3x3)",
                          "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-                         "traffic": None, "launches": n, "avg_launch_ms": ms / n,
+                         "traffic": traffic, "launches": n, "avg_launch_ms": ms / n,
                          "share_of_step_time": (ms * 1e-3) / elapsed},
         }
         if a.cpu_baseline == "auto" and world == 1:

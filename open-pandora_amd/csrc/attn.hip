@@ -24,7 +24,7 @@ struct AttnParams {
   int Nk[2];
   float w[2];
   int nseg;
-  int Nq, heads;
+  int Nq, heads, nqt;
   float scale_log2e;
 };
 
@@ -61,9 +61,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, hh = lane >> 5;
-  const int bh = blockIdx.y;
+  // 1-D grid, XCD-aware: blocks are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
+  // run of ids = all query tiles of the same (frame, head) -> its K/V (re-read by every query tile)
+  // stays in that XCD's L2 instead of being fetched by all eight
+  int wg = blockIdx.x;
+  {
+    const int nwg = gridDim.x, qn = nwg >> 3, rn = nwg & 7, xcd = wg & 7;
+    wg = ((xcd < rn) ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (wg >> 3);
+  }
+  const int bh = wg / p.nqt;
+  const int qt = wg - bh * p.nqt;
   const int b = bh / p.heads, head = bh - b * p.heads;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = qt * 128 + wave * 32;
   int qrow = q0 + ql;
   const bool q_valid = qrow < p.Nq;
   if (!q_valid) qrow = p.Nq - 1;
@@ -354,7 +363,7 @@ extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const voi
   if (B < 1 || heads < 1 || Nq < 1 || Nk1 < 1 || (k2 && Nk2 < 1)) return PM_E_SHAPE;
   if ((q_bs | q_rs | k1_bs | k1_rs | o_bs | o_rs) & 7) return PM_E_SHAPE;
   if (k2 && ((k2_bs | k2_rs) & 7)) return PM_E_SHAPE;
-  if (B * heads > 65535) return PM_E_SHAPE;
+  if (B * heads * ((Nq + 127) / 128) > (1ll << 30)) return PM_E_SHAPE;
   AttnParams p{};
   p.q = q; p.o = o; p.q_bs = q_bs; p.q_rs = q_rs; p.o_bs = o_bs; p.o_rs = o_rs;
   p.k[0] = k1; p.v[0] = v1; p.k_bs[0] = k1_bs; p.k_rs[0] = k1_rs; p.Nk[0] = (int)Nk1; p.w[0] = 1.f;
@@ -362,7 +371,8 @@ extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const voi
   p.nseg = k2 ? 2 : 1;
   p.Nq = (int)Nq; p.heads = (int)heads;
   p.scale_log2e = scale * 1.4426950408889634f;
-  dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)(B * heads));
+  p.nqt = (int)((Nq + 127) / 128);
+  dim3 grid((unsigned)(p.nqt * B * heads));
   PM_DISPATCH_DTYPE(dtype, T,
                     hipLaunchKernelGGL((attn_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, p);
                     return check_launch());

@@ -31,7 +31,7 @@ struct GemmParams {
   int M, N, K;
   int act;
   int out32;
-  int ntiles;
+  int ntiles, mtiles;
   int splits, ktps;  // split-K: number of K slices and K-tiles per slice
   float* ws;         // split-K partial slabs [splits][M][N] f32
   // conv3x3
@@ -88,7 +88,17 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const GemmPara
   const int wg0 = xcd_remap(blockIdx.x, gridDim.x);
   const int split = wg0 % p.splits;
   const int wg = wg0 / p.splits;
-  const int mt = wg / p.ntiles, nt = wg - mt * p.ntiles;
+  // supertile order: workgroups that run together on one XCD (a contiguous run of ids) cover GM row
+  // tiles x several column tiles, so both the A and the W panels they stream stay in that XCD's 4 MiB
+  // L2 (row-major order re-fetched the whole W panel set for every row tile: 9x the algorithmic bytes
+  // on the wide GEGLU GEMM, FETCH_SIZE in profiles/r01/pmc_traffic.md)
+  constexpr int GM = 8;
+  const int grp = wg / (GM * p.ntiles);
+  const int first_m = grp * GM;
+  const int gm = (p.mtiles - first_m < GM) ? p.mtiles - first_m : GM;
+  const int rin = wg - grp * GM * p.ntiles;
+  const int nt = rin / gm;
+  const int mt = first_m + (rin - nt * gm);
   const int m0 = mt * BMT, n0 = nt * BN;
   const int nk_all = (p.K + BK - 1) / BK;
   const int kt0 = split * p.ktps;
@@ -504,15 +514,16 @@ template <typename T, int AMODE, bool A32, bool BIG> static int launch1(const Ge
   constexpr int bm = BIG ? 256 : BM;
   constexpr int nt = BIG ? 512 : 256;
   constexpr int lds = BIG ? 3 * (256 + BN) * BK * 2 : 4 * TILE_BYTES;
-  const int mtiles = (p.M + bm - 1) / bm;
-  const int grid = mtiles * p.ntiles * p.splits;
+  GemmParams q = p;
+  q.mtiles = (p.M + bm - 1) / bm;
+  const int grid = q.mtiles * p.ntiles * p.splits;
   static bool attr_set = false;  // idempotent; a benign race sets the same value twice
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, AMODE, A32, BIG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<T, AMODE, A32, BIG>), dim3(grid), dim3(nt), lds, stream, p);
+  hipLaunchKernelGGL((gemm_kernel<T, AMODE, A32, BIG>), dim3(grid), dim3(nt), lds, stream, q);
   if (p.splits > 1) {
     const int64_t work = (int64_t)p.M * ((p.N + 3) / 4);
     int64_t nb = (work + 255) / 256;
