@@ -42,6 +42,7 @@ extern "C" {
  * so that 16-bit rounding happens once per branch operand instead of once per residual add. */
 #define PM_FLAG_A_F32 1   /* the A operand (activations) is f32; rounded to `dtype` while staging   */
 #define PM_FLAG_OUT_F32 2 /* C and `residual` are f32 (bias/act/residual add and the store in f32) */
+#define PM_FLAG_RES_F32 4 /* `residual` is f32 while C stays 16-bit (last add of a block's stream)  */
 
 /* activation fused into a GEMM / conv epilogue */
 #define PM_ACT_NONE 0

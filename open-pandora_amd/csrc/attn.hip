@@ -10,6 +10,7 @@
 //                      cdna guide §3 "accumulator tile as the next MFMA's operand"); V^T fragments
 //                      come from the row-major V tile through ds_read_b64_tr_b16.
 // Two key/value segments (text, image) are normalised independently and summed (attention.py:128-142).
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace pm {
@@ -53,7 +54,12 @@ template <typename T> __device__ __forceinline__ typename Vec<T>::v8 tr_pair(con
   return u.v;
 }
 
-template <typename T>
+// QB = 32-row query blocks per wave.  QB = 1: 128 query rows per workgroup (short sequences, the
+// two-segment cross-attention).  QB = 2: 256 rows per workgroup - every K / V^T fragment read from LDS
+// feeds two MFMAs and the two blocks' MFMA and softmax chains are independent, so the scheduler can
+// overlap one block's exp/max/convert VALU work with the other's matrix work (the kernel is
+// VALU-issue-bound at head dim 64: ~13 VALU per 32x32x16 MFMA).
+template <typename T, int QB, bool SEG2>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE_BYTES];  // K[2], V[2]
   char* const Ks = smem;
@@ -72,28 +78,37 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   const int bh = wg / p.nqt;
   const int qt = wg - bh * p.nqt;
   const int b = bh / p.heads, head = bh - b * p.heads;
-  const int q0 = qt * 128 + wave * 32;
-  int qrow = q0 + ql;
-  const bool q_valid = qrow < p.Nq;
-  if (!q_valid) qrow = p.Nq - 1;
 
   // Q^T fragments (B operand): element j of k-step s = Q[qrow][16 s + 8 hh + j]
-  const T* qp = reinterpret_cast<const T*>(p.q) + (int64_t)b * p.q_bs + (int64_t)qrow * p.q_rs +
-                head * 64 + 8 * hh;
-  Pack8<T> qf[4];
+  int qrow[QB];
+  bool q_valid[QB];
+  Pack8<T> qf[QB][4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) qf[s].u = ld_global16(qp + 16 * s);
+  for (int qb = 0; qb < QB; ++qb) {
+    qrow[qb] = qt * (128 * QB) + wave * (32 * QB) + qb * 32 + ql;
+    q_valid[qb] = qrow[qb] < p.Nq;
+    if (!q_valid[qb]) qrow[qb] = p.Nq - 1;
+    const T* qp = reinterpret_cast<const T*>(p.q) + (int64_t)b * p.q_bs + (int64_t)qrow[qb] * p.q_rs +
+                  head * 64 + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[qb][s].u = ld_global16(qp + 16 * s);
+  }
 
   // staging coordinates
   const int lc = tid & 7, lr = tid >> 3;  // chunk, row (+32)
 
-  f32x16 out[2];
+  // two-segment (text + image) calls sum the independently normalised segment outputs here
+  f32x16 out[SEG2 ? QB : 1][2];
+  if constexpr (SEG2) {
 #pragma unroll
-  for (int d = 0; d < 2; ++d)
+    for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) out[d][r] = 0.f;
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[qb][d][r] = 0.f;
+  }
 
-  for (int seg = 0; seg < p.nseg; ++seg) {
+  for (int seg = 0; seg < (SEG2 ? p.nseg : 1); ++seg) {
     const int Nk = p.Nk[seg];
     const T* kg = reinterpret_cast<const T*>(p.k[seg]) + (int64_t)b * p.k_bs[seg] + head * 64 + lc * 8;
     const T* vg = reinterpret_cast<const T*>(p.v[seg]) + (int64_t)b * p.k_bs[seg] + head * 64 + lc * 8;
@@ -119,12 +134,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
       }
     };
 
-    f32x16 oacc[2];
+    f32x16 oacc[QB][2];
+    float m_run[QB], l_run[QB];
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+    for (int qb = 0; qb < QB; ++qb) {
+      m_run[qb] = -INFINITY;
+      l_run[qb] = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[qb][d][r] = 0.f;
+    }
 
     load_kv(0, 0);
     __syncthreads();  // drains the DMA (vmcnt) before the barrier
@@ -135,70 +155,80 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
       const char* ks = Ks + buf * KV_TILE_BYTES;
       const char* vs = Vs + buf * KV_TILE_BYTES;
 
-      // ---- S^T = K . Q^T (raw scores, f32) ----
-      f32x16 sacc[2];
+      // ---- S^T = K . Q^T (raw scores, f32); each K fragment serves every query block ----
+      f32x16 sacc[QB][2];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc[qb][kb][r] = 0.f;
         const int row = kb * 32 + ql;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           Pack8<T> kf;
           const int chunk = 2 * s + hh;
           kf.u = *reinterpret_cast<const u32x4*>(ks + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-          sacc[kb] = mfma32(kf.v, qf[s].v, sacc[kb]);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) sacc[qb][kb] = mfma32(kf.v, qf[qb][s].v, sacc[qb][kb]);
         }
       }
-      // sacc[kb][r] <-> key = kt*64 + kb*32 + (r&3) + 8*(r>>2) + 4*hh, query = ql
+      // sacc[qb][kb][r] <-> key = kt*64 + kb*32 + (r&3) + 8*(r>>2) + 4*hh, query = ql of block qb
       if (kt * KV_TILE + KV_TILE > Nk) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = kt * KV_TILE + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+              if (key >= Nk) sacc[qb][kb][r] = -INFINITY;
+            }
+      }
+      // ---- online softmax (base-2 domain) ----
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        float mx = sacc[qb][0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qb][kb][r]);
+        mx = fmaxf(mx, other_half(mx));
+        const float m_new = fmaxf(m_run[qb], mx * p.scale_log2e);
+        // rescale only when some row's running max actually grew (alpha == 1 exactly otherwise)
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run[qb]) != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+          l_run[qb] *= alpha;
+#pragma unroll
+          for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[qb][d][r] *= alpha;
+          m_run[qb] = m_new;
+        }
+        float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int key = kt * KV_TILE + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            if (key >= Nk) sacc[kb][r] = -INFINITY;
+            const float pv = __builtin_amdgcn_exp2f(sacc[qb][kb][r] * p.scale_log2e - m_run[qb]);
+            sacc[qb][kb][r] = pv;
+            psum += pv;
           }
+        l_run[qb] += psum;
       }
-      // ---- online softmax (base-2 domain) ----
-      float mx = sacc[0][0];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
-      mx = fmaxf(mx, other_half(mx));
-      const float m_new = fmaxf(m_run, mx * p.scale_log2e);
-      // rescale only when some row's running max actually grew (alpha == 1 exactly otherwise)
-      if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        l_run *= alpha;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
-        m_run = m_new;
-      }
-      float psum = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(sacc[kb][r] * p.scale_log2e - m_new);
-          sacc[kb][r] = pv;
-          psum += pv;
-        }
-      l_run += psum;
 
-      // ---- O^T += V^T . P^T ----
+      // ---- O^T += V^T . P^T; each V^T fragment serves every query block ----
       const int trow = (lane & 15) >> 2;                 // row inside the 4x16 block
       const int tcol8 = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);  // 16-byte chunk inside the d-block
       const int tsub = (lane & 1) * 8;                   // byte inside the chunk
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
-        Pack8<T> pf;
+        Pack8<T> pf[QB];
         const int kb = s4 >> 1, sp = s4 & 1;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf.e[j] = from_f32<T>(sacc[kb][8 * sp + j]);
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[qb].e[j] = from_f32<T>(sacc[qb][kb][8 * sp + j]);
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           const int r0 = 16 * s4 + 4 * hh + trow;
@@ -207,31 +237,38 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
           const int off0 = r0 * 128 + ((ch ^ (((r0 >> 1) & 1) << 2)) << 4) + tsub;
           const int off1 = r1 * 128 + ((ch ^ (((r1 >> 1) & 1) << 2)) << 4) + tsub;
           typename Vec<T>::v8 vf = tr_pair<T>(vs, off0, off1);
-          oacc[db] = mfma32(vf, pf.v, oacc[db]);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) oacc[qb][db] = mfma32(vf, pf[qb].v, oacc[qb][db]);
         }
       }
       __syncthreads();
     }
-    const float l_tot = l_run + other_half(l_run);
-    const float inv = p.w[seg] / l_tot;
+    // oacc[qb][db][r] <-> d = db*32 + (r&3) + 8*(r>>2) + 4*hh for query row ql of block qb
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+    for (int qb = 0; qb < QB; ++qb) {
+      const float l_tot = l_run[qb] + other_half(l_run[qb]);
+      const float inv = p.w[seg] / l_tot;
+      if constexpr (SEG2) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) out[d][r] += oacc[d][r] * inv;
-  }
-
-  // out[db][r] <-> d = db*32 + (r&3) + 8*(r>>2) + 4*hh for query row ql
-  if (q_valid) {
-    T* op = reinterpret_cast<T*>(p.o) + (int64_t)b * p.o_bs + (int64_t)qrow * p.o_rs + head * 64;
+        for (int d = 0; d < 2; ++d)
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        Pack4<T> ov;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ov.e[e] = from_f32<T>(out[db][4 * g + e]);
-        *reinterpret_cast<u32x2*>(op + db * 32 + 8 * g + 4 * hh) = ov.u;
+          for (int r = 0; r < 16; ++r) out[qb][d][r] += oacc[qb][d][r] * inv;
+        if (seg + 1 < p.nseg) continue;
       }
+      if (q_valid[qb]) {
+        T* op = reinterpret_cast<T*>(p.o) + (int64_t)b * p.o_bs + (int64_t)qrow[qb] * p.o_rs + head * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            Pack4<T> ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              ov.e[e] = from_f32<T>(SEG2 ? out[qb][db][4 * g + e] : oacc[qb][db][4 * g + e] * inv);
+            *reinterpret_cast<u32x2*>(op + db * 32 + 8 * g + 4 * hh) = ov.u;
+          }
+      }
+    }
   }
 }
 
@@ -371,10 +408,23 @@ extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const voi
   p.nseg = k2 ? 2 : 1;
   p.Nq = (int)Nq; p.heads = (int)heads;
   p.scale_log2e = scale * 1.4426950408889634f;
-  p.nqt = (int)((Nq + 127) / 128);
+  // 64 query rows per wave (256 per workgroup) only for very large grids (measured: +2 % at N = 9216,
+  // slower below that because of the coarser tail)
+  static const bool allow_qb2 = [] { const char* e = getenv("PANDORA_ATTN_QB2"); return !(e && e[0] == '0'); }();
+  const bool qb2 = allow_qb2 && !k2 && ((Nq + 255) / 256) * B * heads >= 2048;
+  const int rows = qb2 ? 256 : 128;
+  p.nqt = (int)((Nq + rows - 1) / rows);
   dim3 grid((unsigned)(p.nqt * B * heads));
+  if (qb2)
+    PM_DISPATCH_DTYPE(dtype, T,
+                      hipLaunchKernelGGL((attn_kernel<T, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+                      return check_launch());
+  if (k2)
+    PM_DISPATCH_DTYPE(dtype, T,
+                      hipLaunchKernelGGL((attn_kernel<T, 1, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+                      return check_launch());
   PM_DISPATCH_DTYPE(dtype, T,
-                    hipLaunchKernelGGL((attn_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, p);
+                    hipLaunchKernelGGL((attn_kernel<T, 1, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
                     return check_launch());
 }
 

@@ -30,7 +30,7 @@ struct GemmParams {
   int64_t ldc;
   int M, N, K;
   int act;
-  int out32;
+  int out32, res32;  // f32 output / f32 residual (independent)
   int ntiles, mtiles;
   int splits, ktps;  // split-K: number of K slices and K-tiles per slice
   float* ws;         // split-K partial slabs [splits][M][N] f32
@@ -358,10 +358,10 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const GemmPara
   const int nbase = geglu ? (n0 >> 1) : n0;
   float* stage = reinterpret_cast<float*>(smem);  // [64][STAGE_LD]
   T* __restrict__ Cg = reinterpret_cast<T*>(p.C);
-  const T* __restrict__ Rg = partial ? nullptr : reinterpret_cast<const T*>(p.R);
+  const T* __restrict__ Rg = (partial || p.res32) ? nullptr : reinterpret_cast<const T*>(p.R);
   float* __restrict__ Cf = partial ? p.ws + (int64_t)split * p.M * p.N
                                    : reinterpret_cast<float*>(p.C);  // PM_FLAG_OUT_F32: residual stream
-  const float* __restrict__ Rf = partial ? nullptr : reinterpret_cast<const float*>(p.R);
+  const float* __restrict__ Rf = (partial || !p.res32) ? nullptr : reinterpret_cast<const float*>(p.R);
   const bool out32 = partial || p.out32 != 0;
   const int64_t ldc = partial ? p.N : p.ldc;
   const int cpr = tw >> 3;         // 8-column chunks per row
@@ -387,24 +387,34 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const GemmPara
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(stage + row * STAGE_LD + scol * 8);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(stage + row * STAGE_LD + scol * 8 + 4);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const bool fullr = (n + 8 <= nout);
+        if (Rf != nullptr) {  // f32 residual (the stream)
+          const float* rptr = Rf + (int64_t)m * p.ldr + n;
+          if (fullr && ((p.ldr & 3) == 0)) {
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(rptr);
+            const f32x4 r1 = *reinterpret_cast<const f32x4*>(rptr + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] += r0[e];
+              v[e + 4] += r1[e];
+            }
+          } else {
+            for (int e = 0; e < 8 && n + e < nout; ++e) v[e] += rptr[e];
+          }
+        } else if (Rg != nullptr) {  // 16-bit residual
+          const T* rptr = Rg + (int64_t)m * p.ldr + n;
+          if (fullr && ((p.ldr & 7) == 0)) {
+            Pack8<T> rv;
+            rv.u = ld_global16(rptr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += to_f32(rv.e[e]);
+          } else {
+            for (int e = 0; e < 8 && n + e < nout; ++e) v[e] += to_f32(rptr[e]);
+          }
+        }
         if (out32) {
           float* cptr = Cf + (int64_t)m * ldc + n;
-          const bool full = (n + 8 <= nout) && ((ldc & 3) == 0);
-          if (Rf != nullptr) {
-            const float* rptr = Rf + (int64_t)m * p.ldr + n;
-            if (full && ((p.ldr & 3) == 0)) {
-              const f32x4 r0 = *reinterpret_cast<const f32x4*>(rptr);
-              const f32x4 r1 = *reinterpret_cast<const f32x4*>(rptr + 4);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                v[e] += r0[e];
-                v[e + 4] += r1[e];
-              }
-            } else {
-              for (int e = 0; e < 8 && n + e < nout; ++e) v[e] += rptr[e];
-            }
-          }
-          if (full) {
+          if (fullr && ((ldc & 3) == 0)) {
             *reinterpret_cast<f32x4*>(cptr) = f32x4{v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4*>(cptr + 4) = f32x4{v[4], v[5], v[6], v[7]};
           } else {
@@ -412,19 +422,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const GemmPara
           }
         } else {
           T* cptr = Cg + (int64_t)m * ldc + n;
-          const bool full = (n + 8 <= nout) && ((ldc & 7) == 0);
-          if (Rg != nullptr) {
-            const T* rptr = Rg + (int64_t)m * p.ldr + n;
-            if (full && ((p.ldr & 7) == 0)) {
-              Pack8<T> rv;
-              rv.u = ld_global16(rptr);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += to_f32(rv.e[e]);
-            } else {
-              for (int e = 0; e < 8 && n + e < nout; ++e) v[e] += to_f32(rptr[e]);
-            }
-          }
-          if (full) {
+          if (fullr && ((ldc & 7) == 0)) {
             Pack8<T> ov;
 #pragma unroll
             for (int e = 0; e < 8; ++e) ov.e[e] = from_f32<T>(v[e]);
@@ -463,13 +461,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
     for (int e = 0; e < 4 && n + e < p.N; ++e) {
       float x = v[e] + (p.bias ? p.bias[n + e] : 0.f);
       if (p.act == PM_ACT_SILU) x = silu_f(x);
-      if (p.out32) {
-        if (p.R) x += reinterpret_cast<const float*>(p.R)[m * p.ldr + n + e];
+      if (p.R) x += p.res32 ? reinterpret_cast<const float*>(p.R)[m * p.ldr + n + e]
+                            : to_f32(reinterpret_cast<const T*>(p.R)[m * p.ldr + n + e]);
+      if (p.out32)
         reinterpret_cast<float*>(p.C)[m * p.ldc + n + e] = x;
-      } else {
-        if (p.R) x += to_f32(reinterpret_cast<const T*>(p.R)[m * p.ldr + n + e]);
+      else
         reinterpret_cast<T*>(p.C)[m * p.ldc + n + e] = from_f32<T>(x);
-      }
     }
   }
 }
@@ -567,6 +564,7 @@ extern "C" int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, c
   p.A = A; p.lda = lda; p.Wt = W; p.ldw = ldw; p.bias = bias; p.R = residual; p.ldr = ldr;
   p.C = C; p.ldc = ldc; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
   p.out32 = (flags & PM_FLAG_OUT_F32) ? 1 : 0;
+  p.res32 = (flags & (PM_FLAG_OUT_F32 | PM_FLAG_RES_F32)) ? 1 : 0;
   p.ntiles = (int)((N + BN - 1) / BN);
   p.zero = A;  // dense K tails never occur (K % 8 == 0 and whole chunks only); see kin below
   // A dense K tail (K % 64 != 0) reads chunk-wise: chunks with k >= K take `zero`; any 16 readable
@@ -594,6 +592,7 @@ extern "C" int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const f
   p.A = x; p.lda = ldx; p.Wt = Wp; p.ldw = K; p.bias = bias; p.R = residual; p.ldr = ldr;
   p.C = y; p.ldc = ldy; p.M = (int)M; p.N = (int)Cout; p.K = (int)K; p.act = PM_ACT_NONE;
   p.out32 = (flags & PM_FLAG_OUT_F32) ? 1 : 0;
+  p.res32 = (flags & (PM_FLAG_OUT_F32 | PM_FLAG_RES_F32)) ? 1 : 0;
   p.ntiles = (int)((Cout + BN - 1) / BN);
   p.Hin = (int)H; p.Win = (int)W; p.Hv = (int)Hv; p.Wv = (int)Wv; p.Cin = (int)Cin;
   p.Ho = (int)Ho; p.Wo = (int)Wo; p.stride = stride; p.ups = upsample2x ? 1 : 0;
@@ -620,6 +619,7 @@ extern "C" int pm_conv_temporal_k3(const void* x, int64_t ldx, const void* halo_
   p.A = x; p.lda = ldx; p.Wt = Wp; p.ldw = K; p.bias = bias; p.R = residual; p.ldr = ldr;
   p.C = y; p.ldc = ldy; p.M = (int)M; p.N = (int)Cout; p.K = (int)K; p.act = PM_ACT_NONE;
   p.out32 = (flags & PM_FLAG_OUT_F32) ? 1 : 0;
+  p.res32 = (flags & (PM_FLAG_OUT_F32 | PM_FLAG_RES_F32)) ? 1 : 0;
   p.ntiles = (int)((Cout + BN - 1) / BN);
   p.Cin = (int)Cin; p.F = (int)F; p.P = (int)P; p.halo_lo = halo_lo; p.halo_hi = halo_hi;
   p.zero = zero_page;

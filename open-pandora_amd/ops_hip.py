@@ -51,14 +51,17 @@ class HipOps:
 
     def _gemm_io(self, a, residual, out, M, n_out, stream):
         """flags + output allocation shared by the GEMM family.  `stream=True`: the result belongs to
-        the f32 residual stream (f32 output and f32 residual); an f32 `a` is rounded while staging."""
+        the f32 residual stream (f32 output and f32 residual); an f32 `a` is rounded while staging;
+        an f32 residual with `stream=False` is added in f32 and the sum stored as 16 bit."""
         flags = (capi.PM_FLAG_A_F32 if a.dtype == torch.float32 else 0) | (capi.PM_FLAG_OUT_F32 if stream else 0)
         odt = torch.float32 if stream else self.dtype
         if out is None:
             out = self.empty(M, n_out, dtype=odt)
         assert out.dtype == odt and out.stride(1) == 1
         if residual is not None:
-            assert residual.dtype == odt and residual.stride(1) == 1, (residual.dtype, odt)
+            assert residual.stride(1) == 1 and residual.dtype in (odt, torch.float32), (residual.dtype, odt)
+            if residual.dtype == torch.float32 and not stream:
+                flags |= capi.PM_FLAG_RES_F32
         return flags, out
 
     def empty(self, *shape, dtype=None):

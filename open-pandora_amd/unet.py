@@ -411,7 +411,9 @@ class UNetModel(nn.Module):
             h = ops.gemm(a.view(c.F * P, inner), *e[f"a{which}_out"], residual=h, stream=True)
         y = ops.layernorm(h, *e["ln3"])
         g = ops.gemm(y, e["ff1"][0], e["ff1"][1], act="geglu")
-        return ops.gemm(g, e["ff2"][0], e["ff2"][1], residual=h, stream=True)
+        # the block's last add: its only consumer is proj_out's A operand (16-bit anyway), so the sum
+        # (formed in f32 against the f32 stream) is stored as 16 bit
+        return ops.gemm(g, e["ff2"][0], e["ff2"][1], residual=h)
 
     def _transformer(self, c, mod, x, temporal):
         ops, e = c.ops, c.w[self._names[mod]]

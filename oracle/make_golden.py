@@ -169,11 +169,37 @@ def gen_full(traj):
         save("ddim_full_40x64_s10.npz", **out)
 
 
+def gen_oracle_72x128():
+    """576x1024 (16x72x128 latent): the reference's eager attention materialises a 27 GB f32 score
+    tensor per level-0 block and cannot run in this container, so this fixture is
+    produced by the ORACLE (oracle/unet_ref.py, attention chunked over heads - identical arithmetic per
+    row), which is itself pinned to the reference by every other fixture.  Marked as such in the file."""
+    from oracle import unet_ref
+    from open_pandora_amd import factory
+    torch.set_num_threads(os.cpu_count() or 8)
+    with torch.device("meta"):
+        from open_pandora_amd.unet import UNetModel
+        shapes = {k: tuple(v.shape) for k, v in UNetModel(**dict(factory.UNET_PARAMS, default_fs=10)).state_dict().items()}
+    sd = {k: synth.synth_tensor(k, sh, WEIGHT_SEED) for k, sh in shapes.items()}
+    ins, cond, _ = _small_setup(320, 72, 128)
+    x = torch.cat([ins["x_T"], ins["c_concat"]], 1)
+    t0 = time.time()
+    y = unet_ref.unet_forward(sd, x, torch.tensor([500]), ins["c_crossattn"], torch.tensor([15]))
+    print(f"oracle forward 72x128: {time.time() - t0:.0f}s std {y.std():.4f}")
+    out = {f"cond/{k}": v for k, v in digest(y, n=8192).items()}
+    out["source"] = np.array("oracle (oracle/unet_ref.py); the reference cannot run this size on CPU here")
+    save("unet_full_72x128_oracle.npz", **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--traj", action="store_true")
+    ap.add_argument("--oracle-72x128", action="store_true")
     a = ap.parse_args()
+    if a.oracle_72x128:
+        gen_oracle_72x128()
+        sys.exit(0)
     assert rh.available(), "the reference checkout is required"
     if a.full or a.traj:
         gen_full(a.traj)

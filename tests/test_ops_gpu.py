@@ -427,3 +427,30 @@ def test_large_m_gemm_conv_tconv(hip_ops_factory, dtype):
     wt = rnd(320, 3 * 320, dtype=dtype, scale=960 ** -0.5, seed=9)
     b3 = rnd(320, dtype=torch.float32, seed=10)
     assert rel_err(ops.conv_t3(xt.cuda(), wt.cuda(), b3.cuda(), 16, 2560), REF.conv_t3(xt, wt, b3, 16, 2560)) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_self_64_rows_per_wave(hip_ops_factory, dtype):
+    """Large grids take the 256-query-row workgroup (two 32-row blocks per wave); ragged N and a
+    peaked row in the last tile."""
+    ops = hip_ops_factory(dtype)
+    B, heads, N = 16, 16, 2100  # 9 x 256 = 2304 workgroups
+    C = heads * 64
+    qkv = rnd(B, N, 3 * C, dtype=torch.float32, scale=1.2, seed=1)
+    qkv[3, 2090, C:2 * C] = 5 * qkv[3, 77, :C]  # key 2090 dominates query 77 of batch 3 (all heads)
+    qkv = qkv.to(dtype)
+    want = REF.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
+    d = qkv.cuda()
+    got = ops.attention(d[..., :C], d[..., C:2 * C], d[..., 2 * C:], heads)
+    assert rel_err(got, want) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_f32_residual_16bit_out(hip_ops_factory, dtype):
+    """PM_FLAG_RES_F32: f32 residual added in f32, 16-bit store (also through the split-K reduce)."""
+    ops = hip_ops_factory(dtype)
+    for M, N, K in ((300, 320, 1280), (640, 1280, 5120)):
+        a, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=2)
+        bias, res32 = rnd(N, dtype=torch.float32, seed=3), rnd(M, N, dtype=torch.float32, scale=3.0, seed=4)
+        got = ops.gemm(a.cuda(), w.cuda(), bias.cuda(), res32.cuda())
+        assert got.dtype == dtype and rel_err(got, REF.gemm(a, w, bias, res32)) <= TOL[dtype]
