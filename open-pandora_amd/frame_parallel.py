@@ -8,8 +8,12 @@ object provides to UNetModel:
   reduce_stats   GroupNorm over (T,H,W): all-reduce of 32 x {sum, sumsq} f32 partials (256 B, latency);
   exchange_halo  temporal 3-tap conv: one boundary frame to each neighbour (point-to-point, the clip
                  ends keep zero padding);
-  gather_kv      temporal self-attention: all-gather of the K|V projections along the frame axis
-                 (every query frame attends to all T frames at its pixel).
+  frames_to_pixels / pixels_to_frames
+                 TemporalTransformer: one all-to-all in (after the GroupNorm) and one out (before
+                 proj_out) re-shard frames <-> pixels, so its projections, both temporal
+                 self-attentions and the feed-forward run locally on all T frames of a pixel slice
+                 (moves 2C per token instead of the 2C(N-1) of an all-gather of K|V per attention;
+                 gather_kv is kept as the all-gather form).
 
 The single-GPU result of the same kernels is the oracle for this mode (the reference has no
 counterpart): tests/test_frame_parallel_cpu.py checks equality with world_size 2 on gloo.
@@ -38,7 +42,7 @@ class FrameParallel:
         self.local_frames = total_frames // self.world
         self.frame_offset = self.rank * self.local_frames
         self.backend = dist.get_backend(group)
-        self.calls = {"reduce_stats": 0, "exchange_halo": 0, "gather_kv": 0}
+        self.calls = {"reduce_stats": 0, "exchange_halo": 0, "all_to_all": 0}
 
     # ---- clip-level helpers (sampler boundary) --------------------------------------------------
     def shard_frames(self, x, dim=2):
@@ -80,9 +84,34 @@ class FrameParallel:
             req.wait()
         return lo, hi
 
+    def _a2a(self, src):
+        dst = torch.empty_like(src)
+        _host_staged_sync(src, self.group)
+        dist.all_to_all_single(dst, src, group=self.group)
+        return dst
+
+    def frames_to_pixels(self, t, P):
+        """[F_local*P, C] (my frames, all pixels) -> [F_total*(P/N), C] (all frames, my pixel slice).
+        One all-to-all moves each element once; the whole TemporalTransformer (projections, both
+        temporal self-attentions, feed-forward: all per-pixel) then runs without any exchange."""
+        self.calls["all_to_all"] += 1
+        N, Fl = self.world, self.local_frames
+        assert P % N == 0, f"{P} pixels do not shard over {N} ranks"
+        C = t.shape[1]
+        src = t.view(Fl, N, P // N, C).permute(1, 0, 2, 3).contiguous()  # chunk j -> rank j
+        return self._a2a(src).view(N * Fl * (P // N), C)               # [source rank = frame block, ...]
+
+    def pixels_to_frames(self, t, P):
+        """inverse of frames_to_pixels."""
+        self.calls["all_to_all"] += 1
+        N, Fl = self.world, self.local_frames
+        C = t.shape[1]
+        dst = self._a2a(t.contiguous()).view(N, Fl, P // N, C)          # [source rank = pixel slice, ...]
+        return dst.permute(1, 0, 2, 3).reshape(Fl * P, C)
+
     def gather_kv(self, qkv, inner, P):
         """qkv [F_local, P, 3*inner] (q|k|v): returns k, v views [T, P, inner] over all frames."""
-        self.calls["gather_kv"] += 1
+        self.calls["gather_kv"] = self.calls.get("gather_kv", 0) + 1
         kv_local = qkv[..., inner:].contiguous()
         _host_staged_sync(kv_local, self.group)
         kv_all = torch.empty((self.total_frames,) + tuple(kv_local.shape[1:]), dtype=kv_local.dtype,

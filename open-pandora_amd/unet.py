@@ -382,12 +382,11 @@ class UNetModel(nn.Module):
                                 stream=True)
         return h
 
-    def _block(self, c, e, h, mod, temporal):
+    def _block(self, c, e, h, mod, temporal, F, P, gather=False):
         """BasicTransformerBlock on tokens h [F*P, inner] (attention.py:242-246)."""
         ops = c.ops
-        P = c.H * c.W
         inner, heads = mod.inner, mod.heads
-        v3 = lambda t, n: t.view(c.F, P, n)
+        v3 = lambda t, n: t.view(F, P, n)
         for which in (1, 2):
             y = ops.layernorm(h, *e[f"ln{which}"])
             key = f"a{which}_qkv"
@@ -395,7 +394,7 @@ class UNetModel(nn.Module):
                 qkv = v3(ops.gemm(y, e[key]), 3 * inner)
                 q, k, v = qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:]
                 if temporal:
-                    if c.fp is not None:
+                    if gather:  # frame-sharded without the pixel re-shard: all-gather K|V over frames
                         k, v = c.fp.gather_kv(qkv, inner, P)
                     a = ops.attention_temporal(q, k, v, heads)
                 else:
@@ -405,10 +404,10 @@ class UNetModel(nn.Module):
                 kv_t = ops.gemm(c.ctx_text, e["a2_kv"]).view(1, -1, 2 * inner)
                 k2 = v2 = None
                 if "a2_kv_ip" in e:
-                    kv_i = ops.gemm(c.ctx_img, e["a2_kv_ip"]).view(c.F, -1, 2 * inner)
+                    kv_i = ops.gemm(c.ctx_img, e["a2_kv_ip"]).view(F, -1, 2 * inner)
                     k2, v2 = kv_i[..., :inner], kv_i[..., inner:]
                 a = ops.attention(q, kv_t[..., :inner], kv_t[..., inner:], heads, k2, v2, 1.0)
-            h = ops.gemm(a.view(c.F * P, inner), *e[f"a{which}_out"], residual=h, stream=True)
+            h = ops.gemm(a.view(F * P, inner), *e[f"a{which}_out"], residual=h, stream=True)
         y = ops.layernorm(h, *e["ln3"])
         g = ops.gemm(y, e["ff1"][0], e["ff1"][1], act="geglu")
         # the block's last add: its only consumer is proj_out's A operand (16-bit anyway), so the sum
@@ -417,9 +416,17 @@ class UNetModel(nn.Module):
 
     def _transformer(self, c, mod, x, temporal):
         ops, e = c.ops, c.w[self._names[mod]]
+        F, P = c.F, c.H * c.W
         h = self._gn(c, x, e["norm"], 1e-6, False, not temporal)
+        sharded = temporal and c.fp is not None and P % c.fp.world == 0
+        gather = temporal and c.fp is not None and not sharded  # (pixel count not divisible: tiny maps)
+        if sharded:  # frames <-> pixels: the temporal block needs all T frames of a pixel, nothing else
+            h = c.fp.frames_to_pixels(h, P)
+            F, P = c.fp.total_frames, P // c.fp.world
         h = ops.gemm(h, *e["proj_in"], stream=True)  # the block's own residual stream (f32)
-        h = self._block(c, e, h, mod, temporal)
+        h = self._block(c, e, h, mod, temporal, F, P, gather)
+        if sharded:
+            h = c.fp.pixels_to_frames(h, c.H * c.W)
         return ops.gemm(h, *e["proj_out"], residual=x, stream=True)
 
     def _run(self, c, seq, h):

@@ -1,5 +1,5 @@
 """CPU, world_size 2 on gloo: the frame-sharded forward and DDIM loop (FrameParallel exchanges:
-(T,H,W) GroupNorm statistics, temporal-conv halos, temporal-attention K/V all-gather) reproduce the
+(T,H,W) GroupNorm statistics, temporal-conv halos, frames<->pixels all-to-all around the temporal transformers) reproduce the
 single-process result.  The op table is the oracle's TorchOps (tests only); the same host code runs
 on HipOps + RCCL on the GPUs."""
 import os
@@ -69,8 +69,10 @@ def test_frame_sharded_sampling_matches_single_process(tmp_path, world, S, eta):
     want = _sample(_build(None), None, S, eta)
     err = ((got["y"] - want).norm() / want.norm()).item()
     assert err < 2e-5, err
-    # 2 forwards/step: 105 (T,H,W) GroupNorms, 88 temporal convs, 34 temporal attentions each
-    assert got["calls"] == {"reduce_stats": 105 * 2 * S, "exchange_halo": 88 * 2 * S, "gather_kv": 34 * 2 * S}
+    # 2 forwards/step: 105 (T,H,W) GroupNorms, 88 temporal convs, 17 TemporalTransformers (2 all-to-all) each
+    # (the 1x1-pixel middle block of this 8x8 test latent cannot be pixel-sharded: K|V all-gather there)
+    assert got["calls"] == {"reduce_stats": 105 * 2 * S, "exchange_halo": 88 * 2 * S, "all_to_all": 32 * 2 * S,
+                            "gather_kv": 2 * 2 * S}
 
 
 def _hybrid_worker(rank, world, port, S, eta, out):
@@ -101,4 +103,5 @@ def test_cfg_pair_plus_frame_sharding_matches_single_process(tmp_path, world, S,
         if world == 2:
             assert got["fp_calls"] is None
         else:  # ONE forward per step and rank
-            assert got["fp_calls"] == {"reduce_stats": 105 * S, "exchange_halo": 88 * S, "gather_kv": 34 * S}
+            assert got["fp_calls"] == {"reduce_stats": 105 * S, "exchange_halo": 88 * S, "all_to_all": 32 * S,
+                                       "gather_kv": 2 * S}
