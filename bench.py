@@ -161,6 +161,24 @@ def main():
         elapsed = tt.item()
     assert torch.isfinite(x).all(), "latent went non-finite"
 
+    # first-stage decode of the clip (the step after the loop): reported beside the loop
+    decode_ms = None
+    if world == 1:
+        from open_pandora_amd.autoencoder import AutoencoderKL
+        with torch.device("meta"):
+            ae = AutoencoderKL()
+        ae.load_state_dict({k: synth.synth_tensor(k, tuple(v.shape), 20230211, dev) for k, v in ae.state_dict().items()},
+                           assign=True)
+        ae.bind(ops)
+        z = (0.18215 * x).contiguous()
+        ae.decode_first_stage(z)  # warm-up (weight packing)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        frames = ae.decode_first_stage(z)
+        torch.cuda.synchronize()
+        decode_ms = 1e3 * (time.perf_counter() - t1)
+        assert frames.shape == (1, 3, T, 8 * h, 8 * w) and torch.isfinite(frames).all()
+
     if rank == 0:
         ms, n, fl = ops.summary()
         traffic = None  # per-launch HBM-side bytes of the dominant kernel, from the committed PMC passes
@@ -178,6 +196,8 @@ def main():
                                    f"cfg 4.0 => 2 U-Net forwards/step, 1.44 B-parameter U-Net (BASELINE configs[1] at 320x512)",
                        "latent": [T, h, w], "parallelism": mode},
             "sec_per_2s_video": 50.0 * elapsed / a.steps,
+            "ae_decode_ms_16_frames": decode_ms,
+            "sec_per_2s_video_incl_decode": None if decode_ms is None else 50.0 * elapsed / a.steps + 1e-3 * decode_ms,
             "whole_step_mfma_frac": FLOP_PER_STEP[a.res] / (elapsed / a.steps) / 1e12 / MFMA_PEAK_TFLOPS / world,
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel<A_CONV3X3> (pm_conv2d_3x3)",
                          "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,

@@ -202,6 +202,21 @@ int pm_pack_input(const float* x, const float* cond, void* y, int64_t C1, int64_
 int pm_unpack_output(const void* y, void* out, int64_t C, int64_t F, int64_t P, int dtype,
                      void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * First-stage decoder helpers (AutoencoderKL.decode after the loop,
+ * lvdm/models/autoencoder.py:103-106, ddpm3d.py:630-655).  The decoder's convolutions, GroupNorm+swish
+ * and 1x1 projections run on pm_conv2d_3x3 / pm_groupnorm_* / pm_gemm; two small kernels complete it:
+ *   pm_latent_affine: y[f, p, :] = W . (x[:, f, p] * inv_scale) + b, channels-last and zero-padded to
+ *     Cpad (1/scale_factor and post_quant_conv, ddpm3d.py:641-645 + autoencoder.py:104); x f32 [C, F, P].
+ *   pm_softmax_rows: y = softmax(scale * x) per row, x f32 [M, N] scores -> y [M, N] in `dtype`
+ *     (the single-head, 512-channel mid attention of ae_modules.py:52-75 is QK^T and PV on pm_gemm
+ *     around this kernel); N % 4 == 0.
+ */
+int pm_latent_affine(const float* x, const float* W, const float* b, void* y, int64_t C, int64_t Cpad,
+                     int64_t F, int64_t P, float inv_scale, int dtype, void* stream);
+int pm_softmax_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t M, int64_t N,
+                    float scale, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,216 @@
+"""First-stage decoder on the MI355X kernels: `AutoencoderKL` with the reference's
+constructor (`ddconfig`, `embed_dim`) and state_dict keys (`decoder.*`, `post_quant_conv.*`,
+`encoder.*`, `quant_conv.*`; lvdm/models/autoencoder.py:13-45, ae_modules.py:466-537), and
+`decode_first_stage(z)` with the semantics of LatentDiffusion.decode_first_stage (ddpm3d.py:630-655).
+
+The decoder is run channels-last on the same op table as the U-Net: 3x3 convs (and nearest-x2
+upsample + conv) on pm_conv2d_3x3, GroupNorm(eps 1e-6)+swish on pm_groupnorm_*, 1x1 convs on pm_gemm,
+the f32 residual stream convention of unet.py.  The single-head 512-channel mid attention
+(ae_modules.py:52-75, head dim 512 - not the 64 of pm_attention) is QK^T and PV on pm_gemm around
+pm_softmax_rows, one frame at a time; V's bias is added after PV (softmax rows sum to one).
+The encoder parameters are held for checkpoint compatibility; encode (1-4 frames per generate, with
+its asymmetric stride-2 padding) is not built yet and raises.
+"""
+import torch
+import torch.nn as nn
+
+from . import packing
+
+
+class _ResnetBlock(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(32, cin, eps=1e-6)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.norm2 = nn.GroupNorm(32, cout, eps=1e-6)
+        self.dropout = nn.Dropout(0.0)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        if cin != cout:
+            self.nin_shortcut = nn.Conv2d(cin, cout, 1)
+
+
+class _AttnBlock(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.norm = nn.GroupNorm(32, c, eps=1e-6)
+        self.q, self.k, self.v = nn.Conv2d(c, c, 1), nn.Conv2d(c, c, 1), nn.Conv2d(c, c, 1)
+        self.proj_out = nn.Conv2d(c, c, 1)
+
+
+class _Resample(nn.Module):
+    def __init__(self, c, down):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, stride=2 if down else 1, padding=0 if down else 1)
+
+
+class _Level(nn.Module):
+    pass
+
+
+def _mid(c):
+    m = nn.Module()
+    m.block_1, m.attn_1, m.block_2 = _ResnetBlock(c, c), _AttnBlock(c), _ResnetBlock(c, c)
+    return m
+
+
+class Decoder(nn.Module):
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, z_channels, **ignored):
+        super().__init__()
+        nres = len(ch_mult)
+        block_in = ch * ch_mult[-1]
+        self.conv_in = nn.Conv2d(z_channels, block_in, 3, padding=1)
+        self.mid = _mid(block_in)
+        self.up = nn.ModuleList()
+        for lvl in reversed(range(nres)):
+            up = _Level()
+            up.block, up.attn = nn.ModuleList(), nn.ModuleList()
+            block_out = ch * ch_mult[lvl]
+            for _ in range(num_res_blocks + 1):
+                up.block.append(_ResnetBlock(block_in, block_out))
+                block_in = block_out
+            if lvl != 0:
+                up.upsample = _Resample(block_in, down=False)
+            self.up.insert(0, up)
+        self.norm_out = nn.GroupNorm(32, block_in, eps=1e-6)
+        self.conv_out = nn.Conv2d(block_in, out_ch, 3, padding=1)
+
+
+class Encoder(nn.Module):
+    """Parameter container only (checkpoint keys); see the module docstring."""
+
+    def __init__(self, *, ch, in_channels, ch_mult=(1, 2, 4, 8), num_res_blocks, z_channels, double_z=True, **ignored):
+        super().__init__()
+        self.conv_in = nn.Conv2d(in_channels, ch, 3, padding=1)
+        in_mult = (1,) + tuple(ch_mult)
+        self.down = nn.ModuleList()
+        block_in = ch
+        for lvl in range(len(ch_mult)):
+            d = _Level()
+            d.block, d.attn = nn.ModuleList(), nn.ModuleList()
+            block_in, block_out = ch * in_mult[lvl], ch * ch_mult[lvl]
+            for _ in range(num_res_blocks):
+                d.block.append(_ResnetBlock(block_in, block_out))
+                block_in = block_out
+            if lvl != len(ch_mult) - 1:
+                d.downsample = _Resample(block_in, down=True)
+            self.down.append(d)
+        self.mid = _mid(block_in)
+        self.norm_out = nn.GroupNorm(32, block_in, eps=1e-6)
+        self.conv_out = nn.Conv2d(block_in, 2 * z_channels if double_z else z_channels, 3, padding=1)
+
+
+DDCONFIG = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128,
+                ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)  # inference yaml :57-76
+
+
+class AutoencoderKL(nn.Module):
+    def __init__(self, ddconfig=None, lossconfig=None, embed_dim=4, scale_factor=0.18215, **ignored):
+        super().__init__()
+        dd = dict(ddconfig or DDCONFIG)
+        assert not dd.get("attn_resolutions"), "only the mid attention of the shipped config is built"
+        self.encoder = Encoder(**dd)
+        self.decoder = Decoder(**dd)
+        self.quant_conv = nn.Conv2d(2 * dd["z_channels"], 2 * embed_dim, 1)
+        self.post_quant_conv = nn.Conv2d(embed_dim, dd["z_channels"], 1)
+        self.embed_dim, self.scale_factor = embed_dim, scale_factor
+        self.ops, self._packed = None, None
+
+    def bind(self, ops):
+        self.ops, self._packed = ops, None
+        return self
+
+    def load_state_dict(self, *a, **k):
+        self._packed = None
+        return super().load_state_dict(*a, **k)
+
+    def encode(self, x, **kwargs):
+        raise NotImplementedError("AutoencoderKL.encode is not built yet (DESIGN.md: next row)")
+
+    # ---- kernel-side weights --------------------------------------------------------------------
+    def prepare(self):
+        ops = self.ops
+        dev, dt = ops.device, ops.dtype
+        wt = lambda t: t.detach().to(device=dev, dtype=dt).contiguous()
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        conv = lambda m: (wt(packing.pack_conv3x3(m.weight)), f32(m.bias))
+        lin = lambda m: (wt(m.weight.reshape(m.weight.shape[0], -1)), f32(m.bias))
+        gn = lambda m: (f32(m.weight), f32(m.bias))
+        W = {}
+        for name, m in self.decoder.named_modules():
+            if isinstance(m, _ResnetBlock):
+                W[name] = dict(n1=gn(m.norm1), c1=conv(m.conv1), n2=gn(m.norm2), c2=conv(m.conv2),
+                               skip=lin(m.nin_shortcut) if hasattr(m, "nin_shortcut") else None)
+            elif isinstance(m, _AttnBlock):
+                wv, bv = lin(m.v)
+                W[name] = dict(n=gn(m.norm), q=lin(m.q), k=lin(m.k), v=(wv, bv), o=lin(m.proj_out))
+            elif isinstance(m, _Resample):
+                W[name] = conv(m.conv)
+        d = self.decoder
+        # conv_in reads the latent padded from z_channels to 8 channels (zero weights on the padding)
+        w_in = torch.zeros(d.conv_in.weight.shape[0], 8, 3, 3)
+        w_in[:, :d.conv_in.weight.shape[1]] = d.conv_in.weight.detach().float().cpu()
+        W["conv_in"] = (wt(packing.pack_conv3x3(w_in)), f32(d.conv_in.bias))
+        W["norm_out"], W["conv_out"] = gn(d.norm_out), conv(d.conv_out)
+        W["post_quant"] = (f32(self.post_quant_conv.weight.reshape(self.post_quant_conv.weight.shape[0], -1)),
+                           f32(self.post_quant_conv.bias))
+        self._packed = W
+        return self
+
+    # ---- graph ----------------------------------------------------------------------------------
+    def _res(self, W, x, F, H, Wd):
+        ops = self.ops
+        h = ops.groupnorm(x, *W["n1"], 1e-6, F, True)
+        h = ops.conv3x3(h, *W["c1"], F, H, Wd, stream=True)
+        h = ops.groupnorm(h, *W["n2"], 1e-6, F, True)
+        skip = x if W["skip"] is None else ops.gemm(x, *W["skip"], stream=True)
+        return ops.conv3x3(h, *W["c2"], F, H, Wd, residual=skip, stream=True)
+
+    def _attn(self, W, x, F, P):
+        ops = self.ops
+        C = x.shape[1]
+        h = ops.groupnorm(x, *W["n"], 1e-6, F, False)
+        q, k = ops.gemm(h, *W["q"]), ops.gemm(h, *W["k"])
+        out = ops.empty(F * P, C)
+        for f in range(F):  # one single-head (h*w x h*w) attention per frame
+            sl = slice(f * P, (f + 1) * P)
+            s = ops.gemm(q[sl], k[sl], stream=True)                 # scores f32 [P, P]
+            pmat = ops.softmax_rows(s, C ** -0.5)
+            vt = ops.gemm(W["v"][0], h[sl])                          # V^T without bias [C, P]
+            ops.gemm(pmat, vt, W["v"][1], out=out[sl])               # P V + b_v (rows of P sum to 1)
+        return ops.gemm(out, *W["o"], residual=x, stream=True)
+
+    @torch.no_grad()
+    def decode(self, z, scaled=False, **kwargs):
+        """z (n, 4, h, w) latents (already divided by scale_factor unless scaled=True) -> (n, 3, 8h, 8w)."""
+        if self.ops is None:
+            raise RuntimeError("AutoencoderKL.bind(ops) must be called first (no implicit CPU fallback)")
+        if self._packed is None:
+            self.prepare()
+        ops, W = self.ops, self._packed
+        n, c, hh, ww = z.shape
+        F, H, Wd = n, hh, ww
+        zx = z.to(device=ops.device, dtype=torch.float32).permute(1, 0, 2, 3).reshape(c, n, hh * ww).contiguous()
+        x = ops.latent_affine(zx, *W["post_quant"], (1.0 / self.scale_factor) if scaled else 1.0)
+        h = ops.conv3x3(x, *W["conv_in"], F, H, Wd, stream=True)
+        h = self._res(W["mid.block_1"], h, F, H, Wd)
+        h = self._attn(W["mid.attn_1"], h, F, H * Wd)
+        h = self._res(W["mid.block_2"], h, F, H, Wd)
+        for lvl in reversed(range(len(self.decoder.up))):
+            up = self.decoder.up[lvl]
+            for i in range(len(up.block)):
+                h = self._res(W[f"up.{lvl}.block.{i}"], h, F, H, Wd)
+            if hasattr(up, "upsample"):
+                h = ops.conv3x3(h, *W[f"up.{lvl}.upsample"], F, H, Wd, upsample=True, stream=True)
+                H, Wd = 2 * H, 2 * Wd
+        h = ops.groupnorm(h, *W["norm_out"], 1e-6, F, True)
+        y = ops.conv3x3(h, *W["conv_out"], F, H, Wd, stream=True)           # [F*H*W, 3] f32
+        return ops.unpack_output(y, F, H * Wd).reshape(3, n, H, Wd).permute(1, 0, 2, 3)
+
+    @torch.no_grad()
+    def decode_first_stage(self, z):
+        """LatentDiffusion.decode_first_stage (ddpm3d.py:630-655): z (b, 4, t, h, w) *scaled* latents
+        -> (b, 3, t, 8h, 8w)."""
+        b, c, t, hh, ww = z.shape
+        x = z.permute(0, 2, 1, 3, 4).reshape(b * t, c, hh, ww)
+        y = self.decode(x, scaled=True)
+        return y.reshape(b, t, *y.shape[1:]).permute(0, 2, 1, 3, 4)

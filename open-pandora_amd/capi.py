@@ -51,6 +51,10 @@ SIGNATURES = {
     "pm_pack_input": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                               c_int, c_void_p]),
     "pm_unpack_output": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "pm_latent_affine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                 c_float, c_int, c_void_p]),
+    "pm_softmax_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_float, c_int,
+                                c_void_p]),
 }
 
 _lib = None

@@ -86,9 +86,91 @@ __global__ __launch_bounds__(256) void unpack_output_kernel(const T* __restrict_
     for (int c = 0; c < C; ++c) out[(int64_t)c * FP + i] = y[i * C + c];
 }
 
+// y[m, :] = softmax(scale * x[m, :]) for f32 scores x [M, N] -> 16-bit probabilities; one block per row
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int64_t ldx,
+                                                           T* __restrict__ y, int64_t ldy, int N,
+                                                           float scale_log2e) {
+  __shared__ float red[8];
+  const float* xp = x + (int64_t)blockIdx.x * ldx;
+  T* yp = y + (int64_t)blockIdx.x * ldy;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x * 4; i < N; i += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xp + i);
+    mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale_log2e;
+  float sum = 0.f;
+  for (int i = threadIdx.x * 4; i < N; i += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xp + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sum += __builtin_amdgcn_exp2f(v[e] * scale_log2e - mx);
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  for (int i = threadIdx.x * 4; i < N; i += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xp + i);
+    Pack4<T> o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o.e[e] = from_f32<T>(__builtin_amdgcn_exp2f(v[e] * scale_log2e - mx) * inv);
+    *reinterpret_cast<u32x2*>(yp + i) = o.u;
+  }
+}
+
+// y[f, p, c'] = sum_c W[c', c] * x[c, f, p] * inv_scale + b[c']  for c' < C, zero for C <= c' < Cpad
+template <typename T>
+__global__ __launch_bounds__(256) void latent_affine_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ W,
+                                                            const float* __restrict__ b,
+                                                            T* __restrict__ y, int C, int Cpad,
+                                                            int64_t FP, float inv_scale) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < FP; i += (int64_t)gridDim.x * 256) {
+    for (int co = 0; co < Cpad; ++co) {
+      float acc = 0.f;
+      if (co < C) {
+        acc = b[co];
+        for (int c = 0; c < C; ++c) acc = fmaf(W[co * C + c], x[(int64_t)c * FP + i] * inv_scale, acc);
+      }
+      y[i * Cpad + co] = from_f32<T>(acc);
+    }
+  }
+}
+
 }  // namespace pm
 
 using namespace pm;
+
+extern "C" int pm_softmax_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t M, int64_t N,
+                               float scale, int dtype, void* stream) {
+  if (!x || !y) return PM_E_NULL;
+  if (M < 1 || N < 4 || (N & 3) || (ldx & 3) || (ldy & 3) || ldx < N || ldy < N) return PM_E_SHAPE;
+  PM_DISPATCH_DTYPE(dtype, T,
+                    hipLaunchKernelGGL((softmax_rows_kernel<T>), dim3((unsigned)M), dim3(256), 0,
+                                       (hipStream_t)stream, x, ldx, (T*)y, ldy, (int)N,
+                                       scale * 1.4426950408889634f);
+                    return check_launch());
+}
+
+extern "C" int pm_latent_affine(const float* x, const float* W, const float* b, void* y, int64_t C,
+                                int64_t Cpad, int64_t F, int64_t P, float inv_scale, int dtype,
+                                void* stream) {
+  if (!x || !W || !b || !y) return PM_E_NULL;
+  if (C < 1 || Cpad < C || F < 1 || P < 1) return PM_E_SHAPE;
+  const int64_t FP = F * P;
+  int64_t nb = (FP + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  PM_DISPATCH_DTYPE(dtype, T,
+                    hipLaunchKernelGGL((latent_affine_kernel<T>), dim3((unsigned)nb), dim3(256), 0,
+                                       (hipStream_t)stream, x, W, b, (T*)y, (int)C, (int)Cpad, FP,
+                                       inv_scale);
+                    return check_launch());
+}
 
 extern "C" const char* pm_strerror(int code) {
   switch (code) {

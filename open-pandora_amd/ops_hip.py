@@ -238,6 +238,26 @@ class HipOps:
         capi.check(rc, "pm_pack_input")
         return y
 
+    def latent_affine(self, x, W, b, inv_scale, cpad=8):
+        """x f32 [C, F, P] -> [F*P, cpad]: W . (x * inv_scale) + b, channels-last, zero-padded channels."""
+        C, F, P = x.shape
+        assert x.dtype == torch.float32 and x.is_contiguous() and W.shape == (C, C)
+        y = self.empty(F * P, cpad)
+        rc = self.lib.pm_latent_affine(_ptr(x), _ptr(W), _ptr(b), _ptr(y), C, cpad, F, P, float(inv_scale),
+                                       self.dt, self._stream())
+        capi.check(rc, "pm_latent_affine")
+        return y
+
+    def softmax_rows(self, x, scale):
+        """f32 scores [M, N] -> softmax(scale * x) per row, in the activation dtype."""
+        M, N = x.shape
+        assert x.dtype == torch.float32 and x.stride(1) == 1
+        y = self.empty(M, N)
+        rc = self.lib.pm_softmax_rows(_ptr(x), x.stride(0), _ptr(y), y.stride(0), M, N, float(scale), self.dt,
+                                      self._stream())
+        capi.check(rc, f"pm_softmax_rows M={M} N={N}")
+        return y
+
     def unpack_output(self, y, F, P):
         """[F*P, C] -> [C, F, P] (same dtype as y: 16-bit or f32)."""
         C = y.shape[1]

@@ -35,3 +35,9 @@ def noises(shape, S):
 def digest_of(t, stride, n):
     flat = t.detach().float().reshape(-1)
     return flat[::int(stride)][:n]
+
+
+def ae_latent(T, h, w):
+    """scaled latent (1, 4, T, h, w) as the sampler returns it (std ~ scale_factor)."""
+    n = 4 * T * h * w
+    return (synth.uniform_pm1(n, INPUT_SEED, f"ae/z/{T}x{h}x{w}") * 3 ** 0.5 * 0.18215).reshape(1, 4, T, h, w)

@@ -169,6 +169,31 @@ def gen_full(traj):
         save("ddim_full_40x64_s10.npz", **out)
 
 
+def gen_ae():
+    """First-stage decoder: the real AutoencoderKL on seeded weights."""
+    rh._install_shims()
+    from lvdm.models.autoencoder import AutoencoderKL
+    from open_pandora_amd.autoencoder import DDCONFIG
+    out = {}
+    for tag, ch, T, h, w in (("ch32_3x8x8", 32, 3, 8, 8), ("ch64_2x8x16", 64, 2, 8, 16)):
+        ae = AutoencoderKL(ddconfig=dict(DDCONFIG, ch=ch), lossconfig=rh.AttrDict(target="torch.nn.Identity"),
+                           embed_dim=4).eval()
+        ae.load_state_dict(synth.synth_state_dict(ae, seed=WEIGHT_SEED))
+        z = gr.ae_latent(T, h, w)
+        with torch.no_grad():
+            out[tag] = torch.stack([ae.decode(z[:, :, i] / 0.18215) for i in range(T)], 2).numpy()
+    save("ae_decode_small.npz", **out)
+    torch.set_num_threads(os.cpu_count() or 8)
+    ae = AutoencoderKL(ddconfig=dict(DDCONFIG), lossconfig=rh.AttrDict(target="torch.nn.Identity"), embed_dim=4).eval()
+    ae.load_state_dict(synth.synth_state_dict(ae, seed=WEIGHT_SEED))
+    z = gr.ae_latent(2, 40, 64)
+    t0 = time.time()
+    with torch.no_grad():
+        y = torch.stack([ae.decode(z[:, :, i] / 0.18215) for i in range(2)], 2)
+    print(f"full-width AE decode, 2 frames 40x64 -> 320x512: {time.time() - t0:.0f}s std {y.std():.4f}")
+    save("ae_decode_full_40x64.npz", **{f"frames2/{k}": v for k, v in digest(y, n=8192).items()})
+
+
 def gen_oracle_72x128():
     """576x1024 (16x72x128 latent): the reference's eager attention materialises a 27 GB f32 score
     tensor per level-0 block and cannot run in this container, so this fixture is
@@ -196,7 +221,12 @@ if __name__ == "__main__":
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--traj", action="store_true")
     ap.add_argument("--oracle-72x128", action="store_true")
+    ap.add_argument("--ae", action="store_true")
     a = ap.parse_args()
+    if a.ae:
+        assert rh.available()
+        gen_ae()
+        sys.exit(0)
     if a.oracle_72x128:
         gen_oracle_72x128()
         sys.exit(0)

@@ -159,5 +159,15 @@ class TorchOps:
         C, F, P = xs.shape
         return xs.permute(1, 2, 0).reshape(F * P, C).to(self.dtype)
 
+    def latent_affine(self, x, W, b, inv_scale, cpad=8):
+        C, F, P = x.shape
+        y = torch.einsum("oc,cfp->fpo", _f(W), _f(x) * inv_scale) + _f(b)
+        out = torch.zeros(F * P, cpad)
+        out[:, :C] = y.reshape(F * P, C)
+        return out.to(self.dtype)
+
+    def softmax_rows(self, x, scale):
+        return torch.softmax(_f(x) * scale, dim=-1).to(self.dtype)
+
     def unpack_output(self, y, F, P):
         return y.reshape(F, P, -1).permute(2, 0, 1).contiguous()

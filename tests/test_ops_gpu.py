@@ -454,3 +454,17 @@ def test_gemm_f32_residual_16bit_out(hip_ops_factory, dtype):
         bias, res32 = rnd(N, dtype=torch.float32, seed=3), rnd(M, N, dtype=torch.float32, scale=3.0, seed=4)
         got = ops.gemm(a.cuda(), w.cuda(), bias.cuda(), res32.cuda())
         assert got.dtype == dtype and rel_err(got, REF.gemm(a, w, bias, res32)) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_softmax_rows_and_latent_affine(hip_ops_factory, dtype):
+    ops = hip_ops_factory(dtype)
+    s = rnd(300, 2560, dtype=torch.float32, scale=30.0, seed=1)
+    s[17, 2000] = 400.0  # one dominant entry
+    got = ops.softmax_rows(s.cuda(), 512 ** -0.5)
+    assert rel_err(got, REF.softmax_rows(s, 512 ** -0.5)) <= TOL[dtype]
+    x = rnd(4, 3, 70, dtype=torch.float32, seed=2)
+    W, b = rnd(4, 4, dtype=torch.float32, seed=3), rnd(4, dtype=torch.float32, seed=4)
+    got = ops.latent_affine(x.cuda(), W.cuda(), b.cuda(), 1 / 0.18215)
+    assert got.shape == (210, 8) and rel_err(got, REF.latent_affine(x, W, b, 1 / 0.18215)) <= TOL[dtype]
+    assert got[:, 4:].abs().max().item() == 0

@@ -126,3 +126,31 @@ def test_unet_full_width_forward_72x128(hip_ops_factory, dtype):
     assert err <= FWD_TOL[dtype]
     del pm
     torch.cuda.empty_cache()
+
+
+# ---- first-stage decoder --------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_ae_decode_small_gpu(hip_ops_factory, dtype):
+    from open_pandora_amd.autoencoder import DDCONFIG, AutoencoderKL
+    g = load("ae_decode_small.npz")
+    for tag, ch, T, h, w in (("ch32_3x8x8", 32, 3, 8, 8), ("ch64_2x8x16", 64, 2, 8, 16)):
+        ae = AutoencoderKL(ddconfig=dict(DDCONFIG, ch=ch))
+        ae.load_state_dict(synth.synth_state_dict(ae, seed=gr.WEIGHT_SEED))
+        y = ae.bind(hip_ops_factory(dtype)).decode_first_stage(gr.ae_latent(T, h, w).cuda())
+        err = rel(y.cpu(), g[tag])
+        print(f"\n[parity] ae_decode {tag} {dtype}: rel err {err:.2e}")
+        assert err <= FWD_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_ae_decode_full_width_320x512(hip_ops_factory, dtype):
+    """Full-width AutoencoderKL (83.7 M params), 2 frames of a 40x64 latent -> 320x512 pixels, against
+    the real reference's f32 CPU output (strided digest)."""
+    from open_pandora_amd.autoencoder import AutoencoderKL
+    g = load("ae_decode_full_40x64.npz")
+    ae = AutoencoderKL()
+    ae.load_state_dict(synth.synth_state_dict(ae, seed=gr.WEIGHT_SEED))
+    y = ae.bind(hip_ops_factory(dtype)).decode_first_stage(gr.ae_latent(2, 40, 64).cuda())
+    err, std, gstd = _digest_err(y, g, "frames2")
+    print(f"\n[parity] ae_decode full 320x512 {dtype}: rel err {err:.2e} (std {std:.4f} vs {gstd:.4f})")
+    assert err <= FWD_TOL[dtype]
