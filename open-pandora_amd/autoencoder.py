@@ -188,6 +188,12 @@ class AutoencoderKL(nn.Module):
             self.prepare()
         ops, W = self.ops, self._packed
         n, c, hh, ww = z.shape
+        # the kernels address one operand with 32-bit byte offsets: keep the largest activation
+        # (f32, 128 channels at full pixel resolution) under 2 GiB by decoding a few frames at a time
+        per_frame = 64 * hh * ww * self.decoder.conv_out.weight.shape[1] * 4
+        chunk = max(1, (1 << 31) // per_frame)
+        if n > chunk:
+            return torch.cat([self.decode(z[i:i + chunk], scaled) for i in range(0, n, chunk)], 0)
         F, H, Wd = n, hh, ww
         zx = z.to(device=ops.device, dtype=torch.float32).permute(1, 0, 2, 3).reshape(c, n, hh * ww).contiguous()
         x = ops.latent_affine(zx, *W["post_quant"], (1.0 / self.scale_factor) if scaled else 1.0)

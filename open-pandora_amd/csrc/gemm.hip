@@ -538,6 +538,11 @@ template <typename T, int AMODE> static int launch(const GemmParams& p, int flag
   return launch1<T, AMODE, false, false>(p, stream);
 }
 
+// the loaders address an operand as (64-bit uniform base) + (32-bit lane byte offset)
+static bool fits_u32(int64_t elements, int flags) {
+  return elements * ((flags & PM_FLAG_A_F32) ? 4 : 2) < (1ll << 32);
+}
+
 static int check_common(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K,
                         int act) {
   if (!A || !W || !C) return PM_E_NULL;
@@ -559,6 +564,7 @@ extern "C" int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, c
   int rc = check_common(A, W, C, M, N, K, act);
   if (rc) return rc;
   if ((lda & ((flags & PM_FLAG_A_F32) ? 3 : 7)) || (ldw & 7) || lda < K || ldw < K) return PM_E_SHAPE;
+  if (!fits_u32(M * lda, flags) || N * ldw * 2 >= (1ll << 32)) return PM_E_SHAPE;  // 32-bit lane offsets
   if ((flags & PM_FLAG_OUT_F32) && act == PM_ACT_GEGLU) return PM_E_SHAPE;
   GemmParams p{};
   p.A = A; p.lda = lda; p.Wt = W; p.ldw = ldw; p.bias = bias; p.R = residual; p.ldr = ldr;
@@ -583,6 +589,7 @@ extern "C" int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const f
   if (stride != 1 && stride != 2) return PM_E_SHAPE;
   if (upsample2x && stride != 1) return PM_E_SHAPE;
   if ((Cin & 7) || (ldx & ((flags & PM_FLAG_A_F32) ? 3 : 7)) || ldx < Cin) return PM_E_SHAPE;
+  if (!fits_u32(F * H * W * ldx, flags)) return PM_E_SHAPE;  // 32-bit lane offsets: chunk the frames
   const int64_t Hv = upsample2x ? 2 * H : H, Wv = upsample2x ? 2 * W : W;
   const int64_t Ho = (Hv + stride - 1) / stride, Wo = (Wv + stride - 1) / stride;
   const int64_t M = F * Ho * Wo, K = 9 * Cin;
@@ -612,6 +619,7 @@ extern "C" int pm_conv_temporal_k3(const void* x, int64_t ldx, const void* halo_
   if (!zero_page) return PM_E_NULL;
   if ((Cin & 7) || (ldx & ((flags & PM_FLAG_A_F32) ? 3 : 7)) || ldx < Cin) return PM_E_SHAPE;
   if (Cin % BK) return PM_E_SHAPE;  // one tap per K-tile
+  if (!fits_u32(F * P * ldx, flags)) return PM_E_SHAPE;
   const int64_t M = F * P, K = 3 * Cin;
   int rc = check_common(x, Wp, y, M, Cout, K, PM_ACT_NONE);
   if (rc) return rc;
