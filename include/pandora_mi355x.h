@@ -83,12 +83,15 @@ size_t pm_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int act);
  *   x: [F, H, W, Cin] (ldx = elements per pixel row, >= Cin);  Wp: packed [Cout, 9*Cin] with
  *   k = (ky*3 + kx)*Cin + c;  y: [F, Ho, Wo, Cout] with Ho = H*up/stride (ceil), idem Wo.
  *   upsample2x != 0: the conv reads a virtual (2H, 2W) nearest-neighbour image of x.
+ *   pad_lo: zero rows/columns BEFORE the image (1 = symmetric padding 1; 0 = the (0,1,0,1) padding of
+ *   the first-stage encoder's stride-2 Downsample, ae_modules.py:99-103); one row/column after, always.
+ *   Ho = (H*up + pad_lo - 2) / stride + 1.
  *   epilogue as pm_gemm (bias f32 [Cout]; residual [F*Ho*Wo, Cout] with ldr).
  *   zero_page: >= 16 bytes of device zeros (source of padded taps).
  */
 int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const float* bias,
                   const void* residual, int64_t ldr, void* y, int64_t ldy, int64_t F, int64_t H,
-                  int64_t W, int64_t Cin, int64_t Cout, int stride, int upsample2x,
+                  int64_t W, int64_t Cin, int64_t Cout, int stride, int upsample2x, int pad_lo,
                   const void* zero_page, int flags, int dtype, void* workspace,
                   size_t workspace_bytes, void* stream);
 

@@ -8,8 +8,10 @@ upsample + conv) on pm_conv2d_3x3, GroupNorm(eps 1e-6)+swish on pm_groupnorm_*, 
 the f32 residual stream convention of unet.py.  The single-head 512-channel mid attention
 (ae_modules.py:52-75, head dim 512 - not the 64 of pm_attention) is QK^T and PV on pm_gemm around
 pm_softmax_rows, one frame at a time; V's bias is added after PV (softmax rows sum to one).
-The encoder parameters are held for checkpoint compatibility; encode (1-4 frames per generate, with
-its asymmetric stride-2 padding) is not built yet and raises.
+`encode_first_stage(x)` (1-4 conditioning frames per generate, model.py:690-701) runs the encoder the
+same way: its stride-2 Downsample uses the (0,1,0,1) zero padding through pm_conv2d_3x3's pad_lo = 0;
+quant_conv (1x1 after conv_out) is folded into conv_out's weights at pack time (exact: both linear,
+no padding between them); the posterior sample mean + std * noise is taken on the (n, 4, h, w) latent.
 """
 import torch
 import torch.nn as nn
@@ -123,8 +125,51 @@ class AutoencoderKL(nn.Module):
         self._packed = None
         return super().load_state_dict(*a, **k)
 
+    @torch.no_grad()
+    def encode_moments(self, x):
+        """x (n, 3, H, W) pixels in [-1, 1] -> posterior moments (n, 8, H/8, W/8) f32 [mean | logvar]."""
+        if self.ops is None:
+            raise RuntimeError("AutoencoderKL.bind(ops) must be called first (no implicit CPU fallback)")
+        if self._packed is None:
+            self.prepare()
+        ops, W = self.ops, self._packed
+        n, c, H, Wd = x.shape
+        xs = x.to(device=ops.device, dtype=torch.float32).permute(1, 0, 2, 3).reshape(c, n, H * Wd).contiguous()
+        pad = torch.zeros(8 - c, n, H * Wd, dtype=torch.float32, device=ops.device)
+        h = ops.pack_input(xs, pad)                                   # [n*H*W, 8] (3 channels + zero pad)
+        h = ops.conv3x3(h, *W["enc.conv_in"], n, H, Wd, stream=True)
+        enc = self.encoder
+        for lvl in range(len(enc.down)):
+            for i in range(len(enc.down[lvl].block)):
+                h = self._res(W[f"enc.down.{lvl}.block.{i}"], h, n, H, Wd)
+            if hasattr(enc.down[lvl], "downsample"):
+                h = ops.conv3x3(h, *W[f"enc.down.{lvl}.downsample"], n, H, Wd, stride=2, pad_lo=0, stream=True)
+                H, Wd = H // 2, Wd // 2
+        h = self._res(W["enc.mid.block_1"], h, n, H, Wd)
+        h = self._attn(W["enc.mid.attn_1"], h, n, H * Wd)
+        h = self._res(W["enc.mid.block_2"], h, n, H, Wd)
+        h = ops.groupnorm(h, *W["enc.norm_out"], 1e-6, n, True)
+        m = ops.conv3x3(h, *W["enc.conv_out_q"], n, H, Wd, stream=True)  # conv_out with quant_conv folded in
+        return ops.unpack_output(m, n, H * Wd).reshape(m.shape[1], n, H, Wd).permute(1, 0, 2, 3)
+
     def encode(self, x, **kwargs):
-        raise NotImplementedError("AutoencoderKL.encode is not built yet (DESIGN.md: next row)")
+        return self.encode_moments(x)
+
+    @torch.no_grad()
+    def encode_first_stage(self, x, noise=None):
+        """LatentDiffusion.encode_first_stage + get_first_stage_encoding (ddpm3d.py:596-628):
+        x (b, 3, t, H, W) or (n, 3, H, W) -> scale_factor * posterior sample."""
+        five = x.dim() == 5
+        if five:
+            b, c, t, H, Wd = x.shape
+            x = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, H, Wd)
+        mom = self.encode_moments(x)
+        mean, logvar = torch.chunk(mom, 2, dim=1)
+        noise = torch.randn_like(mean) if noise is None else noise.to(mean)
+        z = self.scale_factor * (mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * noise)
+        if five:
+            z = z.reshape(b, t, *z.shape[1:]).permute(0, 2, 1, 3, 4)
+        return z
 
     # ---- kernel-side weights --------------------------------------------------------------------
     def prepare(self):
@@ -145,6 +190,25 @@ class AutoencoderKL(nn.Module):
                 W[name] = dict(n=gn(m.norm), q=lin(m.q), k=lin(m.k), v=(wv, bv), o=lin(m.proj_out))
             elif isinstance(m, _Resample):
                 W[name] = conv(m.conv)
+        for name, m in self.encoder.named_modules():
+            if isinstance(m, _ResnetBlock):
+                W["enc." + name] = dict(n1=gn(m.norm1), c1=conv(m.conv1), n2=gn(m.norm2), c2=conv(m.conv2),
+                                        skip=lin(m.nin_shortcut) if hasattr(m, "nin_shortcut") else None)
+            elif isinstance(m, _AttnBlock):
+                W["enc." + name] = dict(n=gn(m.norm), q=lin(m.q), k=lin(m.k), v=lin(m.v), o=lin(m.proj_out))
+            elif isinstance(m, _Resample):
+                W["enc." + name] = conv(m.conv)
+        e = self.encoder
+        w_in = torch.zeros(e.conv_in.weight.shape[0], 8, 3, 3)
+        w_in[:, :e.conv_in.weight.shape[1]] = e.conv_in.weight.detach().float().cpu()
+        W["enc.conv_in"] = (wt(packing.pack_conv3x3(w_in)), f32(e.conv_in.bias))
+        W["enc.norm_out"] = gn(e.norm_out)
+        # quant_conv (1x1) o conv_out (3x3): W' = Wq . Wc, b' = Wq . bc + bq (f64 on the host)
+        wq = self.quant_conv.weight.detach().double().cpu().reshape(self.quant_conv.weight.shape[0], -1)
+        wc, bc = e.conv_out.weight.detach().double().cpu(), e.conv_out.bias.detach().double().cpu()
+        w_f = torch.einsum("oc,cikl->oikl", wq, wc).float()
+        b_f = (wq @ bc + self.quant_conv.bias.detach().double().cpu()).float()
+        W["enc.conv_out_q"] = (wt(packing.pack_conv3x3(w_f)), f32(b_f))
         d = self.decoder
         # conv_in reads the latent padded from z_channels to 8 channels (zero weights on the padding)
         w_in = torch.zeros(d.conv_in.weight.shape[0], 8, 3, 3)

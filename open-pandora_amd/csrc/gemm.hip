@@ -35,7 +35,7 @@ struct GemmParams {
   int splits, ktps;  // split-K: number of K slices and K-tiles per slice
   float* ws;         // split-K partial slabs [splits][M][N] f32
   // conv3x3
-  int Hin, Win, Hv, Wv, Cin, Ho, Wo, stride, ups;
+  int Hin, Win, Hv, Wv, Cin, Ho, Wo, stride, ups, pad;  // pad: zero rows/cols before the image (1, or 0)
   // temporal conv
   int F, P;
   const void* halo_lo;
@@ -136,8 +136,8 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const GemmPara
       const int f = m / hw;
       const int rem = m - f * hw;
       const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      a_y[j] = oy * p.stride;  // tap (dy, dx) reads virtual pixel (a_y + dy - 1, a_x + dx - 1)
-      a_x[j] = ox * p.stride;
+      a_y[j] = oy * p.stride + 1 - p.pad;  // tap (dy, dx) reads virtual pixel (a_y + dy - 1, a_x + dx - 1)
+      a_x[j] = ox * p.stride + 1 - p.pad;
       if (AMODE == A_CONV3X3_FAST)  // no upsample: offset of the centre tap, the tap shift is uniform
         a_off[j] = (uint32_t)((((int64_t)f * p.Hin + a_y[j]) * p.Win + a_x[j]) * p.lda * ES + lc * 8 * ES);
       else
@@ -583,15 +583,17 @@ extern "C" int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, c
 extern "C" int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const float* bias,
                              const void* residual, int64_t ldr, void* y, int64_t ldy, int64_t F,
                              int64_t H, int64_t W, int64_t Cin, int64_t Cout, int stride,
-                             int upsample2x, const void* zero_page, int flags, int dtype,
+                             int upsample2x, int pad_lo, const void* zero_page, int flags, int dtype,
                              void* workspace, size_t workspace_bytes, void* stream) {
   if (!zero_page) return PM_E_NULL;
   if (stride != 1 && stride != 2) return PM_E_SHAPE;
   if (upsample2x && stride != 1) return PM_E_SHAPE;
+  if (pad_lo != 0 && pad_lo != 1) return PM_E_SHAPE;
   if ((Cin & 7) || (ldx & ((flags & PM_FLAG_A_F32) ? 3 : 7)) || ldx < Cin) return PM_E_SHAPE;
   if (!fits_u32(F * H * W * ldx, flags)) return PM_E_SHAPE;  // 32-bit lane offsets: chunk the frames
   const int64_t Hv = upsample2x ? 2 * H : H, Wv = upsample2x ? 2 * W : W;
-  const int64_t Ho = (Hv + stride - 1) / stride, Wo = (Wv + stride - 1) / stride;
+  // zero padding: pad_lo rows/cols before, 1 after (pad_lo = 0: the first-stage encoder's (0,1,0,1) pad)
+  const int64_t Ho = (Hv + pad_lo - 2) / stride + 1, Wo = (Wv + pad_lo - 2) / stride + 1;
   const int64_t M = F * Ho * Wo, K = 9 * Cin;
   int rc = check_common(x, Wp, y, M, Cout, K, PM_ACT_NONE);
   if (rc) return rc;
@@ -602,7 +604,7 @@ extern "C" int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const f
   p.res32 = (flags & (PM_FLAG_OUT_F32 | PM_FLAG_RES_F32)) ? 1 : 0;
   p.ntiles = (int)((Cout + BN - 1) / BN);
   p.Hin = (int)H; p.Win = (int)W; p.Hv = (int)Hv; p.Wv = (int)Wv; p.Cin = (int)Cin;
-  p.Ho = (int)Ho; p.Wo = (int)Wo; p.stride = stride; p.ups = upsample2x ? 1 : 0;
+  p.Ho = (int)Ho; p.Wo = (int)Wo; p.stride = stride; p.ups = upsample2x ? 1 : 0; p.pad = pad_lo;
   p.zero = zero_page;
   plan_split(p, workspace, workspace_bytes);
   if (!upsample2x && (Cin % BK) == 0)

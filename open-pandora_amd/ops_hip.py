@@ -82,17 +82,18 @@ class HipOps:
         capi.check(rc, f"pm_gemm M={M} N={N} K={K}")
         return out
 
-    def conv3x3(self, x, wp, bias, F, H, W, stride=1, upsample=False, residual=None, out=None, stream=False):
+    def conv3x3(self, x, wp, bias, F, H, W, stride=1, upsample=False, residual=None, out=None, stream=False,
+                pad_lo=1):
         """x [F*H*W, Cin] -> [F*Ho*Wo, Cout]; wp packed [Cout, 9*Cin]."""
         cin = x.shape[1]
         cout = wp.shape[0]
         assert x.shape[0] == F * H * W and wp.shape[1] == 9 * cin and wp.is_contiguous()
         hv, wv = (2 * H, 2 * W) if upsample else (H, W)
-        ho, wo = (hv + stride - 1) // stride, (wv + stride - 1) // stride
+        ho, wo = (hv + pad_lo - 2) // stride + 1, (wv + pad_lo - 2) // stride + 1
         flags, out = self._gemm_io(x, residual, out, F * ho * wo, cout, stream)
         rc = self.lib.pm_conv2d_3x3(_ptr(x), self._rows(x, True), _ptr(wp), _ptr(bias), _ptr(residual),
                                     residual.stride(0) if residual is not None else 0, _ptr(out),
-                                    out.stride(0), F, H, W, cin, cout, stride, int(upsample),
+                                    out.stride(0), F, H, W, cin, cout, stride, int(upsample), int(pad_lo),
                                     _ptr(self.zero_page), flags, self.dt, _ptr(self.workspace),
                                     self.ws_bytes, self._stream())
         capi.check(rc, f"pm_conv2d_3x3 F={F} H={H} W={W} Cin={cin} Cout={cout}")

@@ -10,6 +10,7 @@ Reference call sites (relative to /root/reference/DynamiCrafter/lvdm):
   ResnetBlock.forward  modules/networks/ae_modules.py:194-215 (temb is None in the decoder)
   AttnBlock.forward    modules/networks/ae_modules.py:52-75 (single head over h*w, scale c^-0.5)
   Upsample.forward     modules/networks/ae_modules.py:119-123 (nearest x2 then conv)
+  Encoder.forward      modules/networks/ae_modules.py:430-464; Downsample :99-103 (pad (0,1,0,1), stride 2)
 """
 import torch
 import torch.nn.functional as F
@@ -45,6 +46,36 @@ def attn_block(sd, p, x):
     v = v.reshape(b, c, hh * ww)
     h = torch.bmm(v, w_.permute(0, 2, 1)).reshape(b, c, hh, ww)
     return x + _conv(sd, p + ".proj_out", h, padding=0)
+
+
+@torch.no_grad()
+def ae_encode_moments(sd, x, prefix=""):
+    """x (n, 3, H, W) pixels -> (n, 8, H/8, W/8) posterior moments [mean | logvar]
+    (Encoder.forward ae_modules.py:430-464, Downsample :99-103, quant_conv autoencoder.py:98-101)."""
+    sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    h = _conv(sd, "encoder.conv_in", x.float())
+    levels = sorted({int(k.split(".")[2]) for k in sd if k.startswith("encoder.down.")})
+    for lvl in levels:
+        i = 0
+        while f"encoder.down.{lvl}.block.{i}.norm1.weight" in sd:
+            h = resnet_block(sd, f"encoder.down.{lvl}.block.{i}", h)
+            i += 1
+        if f"encoder.down.{lvl}.downsample.conv.weight" in sd:
+            h = F.pad(h, (0, 1, 0, 1), mode="constant", value=0)
+            h = F.conv2d(h, sd[f"encoder.down.{lvl}.downsample.conv.weight"].float(),
+                         sd[f"encoder.down.{lvl}.downsample.conv.bias"].float(), stride=2)
+    h = resnet_block(sd, "encoder.mid.block_1", h)
+    h = attn_block(sd, "encoder.mid.attn_1", h)
+    h = resnet_block(sd, "encoder.mid.block_2", h)
+    h = _conv(sd, "encoder.conv_out", _swish(_norm(sd, "encoder.norm_out", h)))
+    return _conv(sd, "quant_conv", h, padding=0)
+
+
+def ae_sample_latent(moments, noise, scale_factor=0.18215):
+    """DiagonalGaussianDistribution.sample (distributions.py:24-42) + get_first_stage_encoding
+    (ddpm3d.py:596-604): scale_factor * (mean + exp(0.5 clamp(logvar)) * noise)."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    return scale_factor * (mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * noise)
 
 
 @torch.no_grad()

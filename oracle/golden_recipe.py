@@ -41,3 +41,8 @@ def ae_latent(T, h, w):
     """scaled latent (1, 4, T, h, w) as the sampler returns it (std ~ scale_factor)."""
     n = 4 * T * h * w
     return (synth.uniform_pm1(n, INPUT_SEED, f"ae/z/{T}x{h}x{w}") * 3 ** 0.5 * 0.18215).reshape(1, 4, T, h, w)
+
+
+def ae_pixels(n, H, W):
+    """conditioning frames (n, 3, H, W) in [-1, 1]."""
+    return synth.uniform_pm1(n * 3 * H * W, INPUT_SEED, f"ae/x/{n}x{H}x{W}").reshape(n, 3, H, W)

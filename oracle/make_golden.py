@@ -182,6 +182,7 @@ def gen_ae():
         z = gr.ae_latent(T, h, w)
         with torch.no_grad():
             out[tag] = torch.stack([ae.decode(z[:, :, i] / 0.18215) for i in range(T)], 2).numpy()
+            out["enc/" + tag] = ae.encode(gr.ae_pixels(T, 8 * h, 8 * w)).parameters.numpy()  # posterior moments
     save("ae_decode_small.npz", **out)
     torch.set_num_threads(os.cpu_count() or 8)
     ae = AutoencoderKL(ddconfig=dict(DDCONFIG), lossconfig=rh.AttrDict(target="torch.nn.Identity"), embed_dim=4).eval()

@@ -56,13 +56,15 @@ class TorchOps:
             y = y + _f(residual)
         return self._out(y, out)
 
-    def conv3x3(self, x, wp, bias, F, H, W, stride=1, upsample=False, residual=None, out=None, stream=False):
+    def conv3x3(self, x, wp, bias, F, H, W, stride=1, upsample=False, residual=None, out=None, stream=False,
+                pad_lo=1):
         cin, cout = x.shape[1], wp.shape[0]
         xi = _f(x).reshape(F, H, W, cin).permute(0, 3, 1, 2)
         if upsample:
             xi = F_.interpolate(xi, scale_factor=2, mode="nearest")
         w = _f(wp).reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)  # -> [Cout, Cin, ky, kx]
-        y = F_.conv2d(xi, w, _f(bias), stride=stride, padding=1)
+        xi = F_.pad(xi, (pad_lo, 1, pad_lo, 1))  # (left, right, top, bottom)
+        y = F_.conv2d(xi, w, _f(bias), stride=stride, padding=0)
         y = y.permute(0, 2, 3, 1).reshape(-1, cout)
         if residual is not None:
             y = y + _f(residual)

@@ -25,6 +25,14 @@ def test_ae_decode_small(tag, ch, T, h, w):
     ae.load_state_dict(sd)
     y = ae.bind(TorchOps()).decode_first_stage(z)
     assert y.shape == (1, 3, T, 8 * h, 8 * w) and rel(y, g) < 2e-5
+    # encoder: posterior moments of T frames, then the reparameterised, scaled sample
+    gm = load("ae_decode_small.npz")["enc/" + tag]
+    px = gr.ae_pixels(T, 8 * h, 8 * w)
+    assert rel(ae_ref.ae_encode_moments(sd, px), gm) < 2e-5
+    mom = ae.encode_moments(px)
+    assert mom.shape == (T, 8, h, w) and rel(mom, gm) < 2e-5
+    noise = gr.ae_latent(T, h, w)[0].permute(1, 0, 2, 3)
+    assert rel(ae.encode_first_stage(px, noise), ae_ref.ae_sample_latent(torch.as_tensor(gm), noise)) < 2e-5
 
 
 def test_ae_state_dict_contract_and_guards():
@@ -37,3 +45,5 @@ def test_ae_state_dict_contract_and_guards():
     assert tuple(sd["encoder.down.0.downsample.conv.weight"].shape) == (128, 128, 3, 3)
     with pytest.raises(RuntimeError):
         AutoencoderKL(ddconfig=dict(DDCONFIG, ch=32)).decode(torch.zeros(1, 4, 8, 8))
+    with pytest.raises(RuntimeError):
+        AutoencoderKL(ddconfig=dict(DDCONFIG, ch=32)).encode_moments(torch.zeros(1, 3, 64, 64))

@@ -468,3 +468,17 @@ def test_softmax_rows_and_latent_affine(hip_ops_factory, dtype):
     got = ops.latent_affine(x.cuda(), W.cuda(), b.cuda(), 1 / 0.18215)
     assert got.shape == (210, 8) and rel_err(got, REF.latent_affine(x, W, b, 1 / 0.18215)) <= TOL[dtype]
     assert got[:, 4:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_asymmetric_pad_stride2(hip_ops_factory, dtype):
+    """pad_lo = 0: the (0,1,0,1) zero padding of the first-stage encoder's Downsample."""
+    ops = hip_ops_factory(dtype)
+    for F, H, W, Cin, Cout in ((2, 8, 6, 64, 64), (1, 16, 24, 128, 128), (2, 8, 8, 8, 32)):
+        x = rnd(F * H * W, Cin, dtype=dtype, seed=1)
+        w = rnd(Cout, Cin, 3, 3, dtype=dtype, scale=(9 * Cin) ** -0.5, seed=2)
+        bias = rnd(Cout, dtype=torch.float32, seed=3)
+        xi = torch.nn.functional.pad(x.float().reshape(F, H, W, Cin).permute(0, 3, 1, 2), (0, 1, 0, 1))
+        want = torch.nn.functional.conv2d(xi, w.float(), bias, stride=2).permute(0, 2, 3, 1).reshape(-1, Cout)
+        got = ops.conv3x3(x.cuda(), packing.pack_conv3x3(w).cuda(), bias.cuda(), F, H, W, stride=2, pad_lo=0)
+        assert got.shape == want.shape and rel_err(got, want) <= TOL[dtype]

@@ -140,6 +140,10 @@ def test_ae_decode_small_gpu(hip_ops_factory, dtype):
         err = rel(y.cpu(), g[tag])
         print(f"\n[parity] ae_decode {tag} {dtype}: rel err {err:.2e}")
         assert err <= FWD_TOL[dtype]
+        mom = ae.encode_moments(gr.ae_pixels(T, 8 * h, 8 * w).cuda())
+        err = rel(mom.cpu(), g["enc/" + tag])
+        print(f"\n[parity] ae_encode moments {tag} {dtype}: rel err {err:.2e}")
+        assert err <= FWD_TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
