@@ -7,7 +7,7 @@ import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpandora_mi355x.so")
+LIB_PATH = os.environ.get("PANDORA_LIB", os.path.join(HERE, "libpandora_mi355x.so"))  # override: kernel experiments
 
 PM_F16, PM_BF16, PM_F32 = 1, 2, 3
 PM_FLAG_A_F32, PM_FLAG_OUT_F32, PM_FLAG_RES_F32 = 1, 2, 4

@@ -296,18 +296,24 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const GemmPara
     }
     const char* as = As + buf * STAGE_BYTES + a_frag;
     const char* bs = Bs + buf * STAGE_BYTES + b_frag;
+    // all 16 fragment reads of the K-tile are issued first (64 VGPRs), so the MFMAs of k-step 0 start
+    // as soon as ITS operands land and the reads of k-step 1 are hidden behind them; written per
+    // k-step the compiler serialises read -> lgkmcnt(0) -> MFMA four times per tile
+    Pack8<T> a[2][4], b[2][4];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      Pack8<T> a[4], b[4];
       const int slot = ks ? slot1 : slot0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i].u = *reinterpret_cast<const u32x4*>(as + i * 2048 + slot);
+      for (int i = 0; i < 4; ++i) a[ks][i].u = *reinterpret_cast<const u32x4*>(as + i * 2048 + slot);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j].u = *reinterpret_cast<const u32x4*>(bs + j * 2048 + slot);
+      for (int j = 0; j < 4; ++j) b[ks][j].u = *reinterpret_cast<const u32x4*>(bs + j * 2048 + slot);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(a[i].v, b[j].v, acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(a[ks][i].v, b[ks][j].v, acc[i][j]);
     }
     if constexpr (BIG) {
       buf = (buf == 2) ? 0 : buf + 1;
