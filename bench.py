@@ -42,7 +42,8 @@ class TimedOps:
         y = self._ops.conv3x3(x, wp, bias, F, H, W, **kw)
         e1.record()
         self.events.append((e0, e1))
-        self.flops += 2.0 * y.shape[0] * y.shape[1] * wp.shape[1]
+        out = y[0] if isinstance(y, tuple) else y  # (out, GroupNorm totals) when stats are fused
+        self.flops += 2.0 * out.shape[0] * out.shape[1] * wp.shape[1]
         return y
 
     def summary(self):

@@ -66,7 +66,16 @@ int pm_abi_version(void);
 int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
             const void* residual, int64_t ldr, void* C, int64_t ldc, int64_t M, int64_t N,
             int64_t K, int act, int flags, int dtype, void* workspace, size_t workspace_bytes,
-            void* stream);
+            float* colstats, void* stream);
+
+/* Fused GroupNorm statistics.  When `colstats` is not NULL the GEMM-family epilogue also writes, per
+ * 128-row output tile and output column, {sum, sum of squares} of exactly the values it stores:
+ * colstats [ceil(M/128)][Nout][2] f32 (the call then runs unsplit).  pm_groupnorm_finalize_colstats turns
+ * them into GroupNorm totals [NI][groups][2] for NI instances of mtiles/NI consecutive row tiles each
+ * (per-frame statistics: rows per frame % 128 == 0; (T,H,W): NI = 1), replacing pm_groupnorm_stats' read
+ * pass over the tensor for the GroupNorm that follows a conv (openaimodel3d.py:178-183,258-269). */
+int pm_groupnorm_finalize_colstats(const float* colstats, float* totals, int64_t mtiles, int64_t C,
+                                   int64_t NI, int groups, void* stream);
 
 /* Split-K scratch.  GEMM-shaped calls whose output has too few 128x128 tiles to fill 256 CUs (the
  * deep U-Net levels: M = 640..2560 rows, K up to 23040) split the K loop over several workgroups that
@@ -93,7 +102,7 @@ int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const float* bias,
                   const void* residual, int64_t ldr, void* y, int64_t ldy, int64_t F, int64_t H,
                   int64_t W, int64_t Cin, int64_t Cout, int stride, int upsample2x, int pad_lo,
                   const void* zero_page, int flags, int dtype, void* workspace,
-                  size_t workspace_bytes, void* stream);
+                  size_t workspace_bytes, float* colstats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * pm_conv_temporal_k3: Conv3d kernel (3,1,1), padding (1,0,0) = 3-tap conv along the frame axis.
@@ -107,7 +116,7 @@ int pm_conv_temporal_k3(const void* x, int64_t ldx, const void* halo_lo, const v
                         const void* Wp, const float* bias, const void* residual, int64_t ldr,
                         void* y, int64_t ldy, int64_t F, int64_t P, int64_t Cin, int64_t Cout,
                         const void* zero_page, int flags, int dtype, void* workspace,
-                  size_t workspace_bytes, void* stream);
+                  size_t workspace_bytes, float* colstats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm(32 groups) on channels-last data, optional fused SiLU.

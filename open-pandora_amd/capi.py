@@ -20,14 +20,15 @@ SIGNATURES = {
     "pm_abi_version": (c_int, []),
     "pm_gemm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                         c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_size_t,
-                        c_void_p]),
+                        c_void_p, c_void_p]),
+    "pm_groupnorm_finalize_colstats": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "pm_gemm_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
     "pm_conv2d_3x3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                               c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int,
-                              c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+                              c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "pm_conv_temporal_k3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64,
-                                    c_int64, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+                                    c_int64, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "pm_groupnorm_nchunks": (c_int64, [c_int64, c_int64]),
     "pm_groupnorm_stats": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                    c_int, c_int, c_void_p]),

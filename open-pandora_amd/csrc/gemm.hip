@@ -34,6 +34,7 @@ struct GemmParams {
   int ntiles, mtiles;
   int splits, ktps;  // split-K: number of K slices and K-tiles per slice
   float* ws;         // split-K partial slabs [splits][M][N] f32
+  float* colstats;   // optional [mtiles][Nout][2]: per-row-tile column {sum, sum of squares} of the output
   // conv3x3
   int Hin, Win, Hv, Wv, Cin, Ho, Wo, stride, ups, pad;  // pad: zero rows/cols before the image (1, or 0)
   // temporal conv
@@ -373,6 +374,11 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const GemmPara
   const int cpr = tw >> 3;         // 8-column chunks per row
   const int rpp = NT / cpr;        // rows per pass
   const int scol = tid % cpr, srow = tid / cpr;
+  // fused GroupNorm statistics of the NEXT layer: column sums of exactly the values stored (f32)
+  const bool want_stats = (p.colstats != nullptr) && !partial;
+  float cs[8], cq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.f;
 
   for (int half = 0; half < WMW; ++half) {
     if (wm == half) {
@@ -418,6 +424,14 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const GemmPara
             for (int e = 0; e < 8 && n + e < nout; ++e) v[e] += to_f32(rptr[e]);
           }
         }
+        if (want_stats) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (n + e < nout) {
+              cs[e] += v[e];
+              cq[e] = fmaf(v[e], v[e], cq[e]);
+            }
+        }
         if (out32) {
           float* cptr = Cf + (int64_t)m * ldc + n;
           if (fullr && ((ldc & 3) == 0)) {
@@ -440,6 +454,28 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const GemmPara
       }
     }
     __syncthreads();
+  }
+  if (want_stats) {  // reduce the rpp row-lanes of every column in a fixed order (deterministic)
+    float* red = stage;  // [rpp][tw][2]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[((srow * tw) + scol * 8 + e) * 2] = cs[e];
+      red[((srow * tw) + scol * 8 + e) * 2 + 1] = cq[e];
+    }
+    __syncthreads();
+    if (tid < tw) {
+      float a = 0.f, b = 0.f;
+      for (int r = 0; r < rpp; ++r) {
+        a += red[(r * tw + tid) * 2];
+        b += red[(r * tw + tid) * 2 + 1];
+      }
+      const int n = nbase + tid;
+      if (n < nout) {
+        float* dst = p.colstats + ((int64_t)mt * nout + n) * 2;
+        dst[0] = a;
+        dst[1] = b;
+      }
+    }
   }
 }
 
@@ -504,6 +540,10 @@ static void plan_split(GemmParams& p, void* workspace, size_t workspace_bytes) {
   (void)init;
   int ktps;
   int s = choose_splits(p.M, p.N, p.K, p.act, &ktps);
+  if (p.colstats != nullptr) {  // fused statistics live in the main kernel's epilogue
+    s = 1;
+    ktps = (p.K + BK - 1) / BK;
+  }
   if (s > 1 && (workspace == nullptr || workspace_bytes < (size_t)s * p.M * p.N * sizeof(float))) {
     s = 1;  // no (or too small a) workspace: run unsplit
     ktps = (p.K + BK - 1) / BK;
@@ -566,7 +606,7 @@ using namespace pm;
 extern "C" int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                        const void* residual, int64_t ldr, void* C, int64_t ldc, int64_t M,
                        int64_t N, int64_t K, int act, int flags, int dtype, void* workspace,
-                       size_t workspace_bytes, void* stream) {
+                       size_t workspace_bytes, float* colstats, void* stream) {
   int rc = check_common(A, W, C, M, N, K, act);
   if (rc) return rc;
   if ((lda & ((flags & PM_FLAG_A_F32) ? 3 : 7)) || (ldw & 7) || lda < K || ldw < K) return PM_E_SHAPE;
@@ -577,6 +617,7 @@ extern "C" int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, c
   p.C = C; p.ldc = ldc; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
   p.out32 = (flags & PM_FLAG_OUT_F32) ? 1 : 0;
   p.res32 = (flags & (PM_FLAG_OUT_F32 | PM_FLAG_RES_F32)) ? 1 : 0;
+  p.colstats = colstats;
   p.ntiles = (int)((N + BN - 1) / BN);
   p.zero = A;  // dense K tails never occur (K % 8 == 0 and whole chunks only); see kin below
   // A dense K tail (K % 64 != 0) reads chunk-wise: chunks with k >= K take `zero`; any 16 readable
@@ -590,7 +631,7 @@ extern "C" int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const f
                              const void* residual, int64_t ldr, void* y, int64_t ldy, int64_t F,
                              int64_t H, int64_t W, int64_t Cin, int64_t Cout, int stride,
                              int upsample2x, int pad_lo, const void* zero_page, int flags, int dtype,
-                             void* workspace, size_t workspace_bytes, void* stream) {
+                             void* workspace, size_t workspace_bytes, float* colstats, void* stream) {
   if (!zero_page) return PM_E_NULL;
   if (stride != 1 && stride != 2) return PM_E_SHAPE;
   if (upsample2x && stride != 1) return PM_E_SHAPE;
@@ -608,6 +649,7 @@ extern "C" int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const f
   p.C = y; p.ldc = ldy; p.M = (int)M; p.N = (int)Cout; p.K = (int)K; p.act = PM_ACT_NONE;
   p.out32 = (flags & PM_FLAG_OUT_F32) ? 1 : 0;
   p.res32 = (flags & (PM_FLAG_OUT_F32 | PM_FLAG_RES_F32)) ? 1 : 0;
+  p.colstats = colstats;
   p.ntiles = (int)((Cout + BN - 1) / BN);
   p.Hin = (int)H; p.Win = (int)W; p.Hv = (int)Hv; p.Wv = (int)Wv; p.Cin = (int)Cin;
   p.Ho = (int)Ho; p.Wo = (int)Wo; p.stride = stride; p.ups = upsample2x ? 1 : 0; p.pad = pad_lo;
@@ -623,7 +665,7 @@ extern "C" int pm_conv_temporal_k3(const void* x, int64_t ldx, const void* halo_
                                    const void* residual, int64_t ldr, void* y, int64_t ldy,
                                    int64_t F, int64_t P, int64_t Cin, int64_t Cout,
                                    const void* zero_page, int flags, int dtype, void* workspace,
-                                   size_t workspace_bytes, void* stream) {
+                                   size_t workspace_bytes, float* colstats, void* stream) {
   if (!zero_page) return PM_E_NULL;
   if ((Cin & 7) || (ldx & ((flags & PM_FLAG_A_F32) ? 3 : 7)) || ldx < Cin) return PM_E_SHAPE;
   if (Cin % BK) return PM_E_SHAPE;  // one tap per K-tile
@@ -636,6 +678,7 @@ extern "C" int pm_conv_temporal_k3(const void* x, int64_t ldx, const void* halo_
   p.C = y; p.ldc = ldy; p.M = (int)M; p.N = (int)Cout; p.K = (int)K; p.act = PM_ACT_NONE;
   p.out32 = (flags & PM_FLAG_OUT_F32) ? 1 : 0;
   p.res32 = (flags & (PM_FLAG_OUT_F32 | PM_FLAG_RES_F32)) ? 1 : 0;
+  p.colstats = colstats;
   p.ntiles = (int)((Cout + BN - 1) / BN);
   p.Cin = (int)Cin; p.F = (int)F; p.P = (int)P; p.halo_lo = halo_lo; p.halo_hi = halo_hi;
   p.zero = zero_page;

@@ -111,6 +111,33 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restri
   }
 }
 
+// grid (groups, NI); block 256: GroupNorm totals from the column statistics a GEMM-family epilogue left
+// behind ([mtiles][C][2] per 128-row tile): instance i owns row tiles [i*tpi, (i+1)*tpi), group g the
+// channels [g*cpg, (g+1)*cpg).  Fixed summation order (per-thread strided, then thread 0..255).
+__global__ __launch_bounds__(256) void gn_finalize_colstats_kernel(const float* __restrict__ colstats,
+                                                                   float* __restrict__ totals, int tpi,
+                                                                   int C, int groups) {
+  __shared__ float red[512];
+  const int g = blockIdx.x, inst = blockIdx.y;
+  const int cpg = C / groups;
+  const int n = tpi * cpg;
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int t = i / cpg, c = i - t * cpg;
+    const float* src = colstats + (((int64_t)inst * tpi + t) * C + g * cpg + c) * 2;
+    a += src[0];
+    b += src[1];
+  }
+  red[threadIdx.x] = a;
+  red[256 + threadIdx.x] = b;
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    float t = 0.f;
+    for (int j = 0; j < 256; ++j) t += red[threadIdx.x * 256 + j];
+    totals[((int64_t)inst * groups + g) * 2 + threadIdx.x] = t;
+  }
+}
+
 // grid (nblocks, NI); block 256.  sh: scale[C], shift[C]
 template <typename TI, typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const TI* __restrict__ x, int64_t ldx,
@@ -279,6 +306,15 @@ extern "C" int pm_groupnorm_stats(const void* x, int64_t ldx, float* partials, f
   hipStream_t st = (hipStream_t)stream;
   if (in_dtype == PM_F32) return launch_stats<float>(x, ldx, partials, totals, NI, P, C, groups, st);
   PM_DISPATCH_DTYPE(in_dtype, T, return launch_stats<T>(x, ldx, partials, totals, NI, P, C, groups, st));
+}
+
+extern "C" int pm_groupnorm_finalize_colstats(const float* colstats, float* totals, int64_t mtiles,
+                                              int64_t C, int64_t NI, int groups, void* stream) {
+  if (!colstats || !totals) return PM_E_NULL;
+  if (NI < 1 || mtiles < NI || (mtiles % NI) || C < 1 || groups < 1 || (C % groups) || NI > 65535) return PM_E_SHAPE;
+  hipLaunchKernelGGL(gn_finalize_colstats_kernel, dim3((unsigned)groups, (unsigned)NI), dim3(256), 0,
+                     (hipStream_t)stream, colstats, totals, (int)(mtiles / NI), (int)C, groups);
+  return check_launch();
 }
 
 extern "C" int pm_groupnorm_apply(const void* x, int64_t ldx, const float* totals,

@@ -67,23 +67,50 @@ class HipOps:
     def empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.dtype, device=self.device)
 
+    # fused GroupNorm statistics: `stats=(NI, groups)` on a GEMM-family op returns (out, totals) where
+    # totals [NI, groups, 2] are the {sum, sumsq} of the stored output per instance (NI consecutive row
+    # blocks) and group; taken from the epilogue's column sums when every instance is a whole number of
+    # 128-row tiles, else by the ordinary statistics pass over the output.
+    def _stats_begin(self, M, n_out, stats, K=0):
+        if stats is None:
+            return None
+        NI, groups = stats
+        if M % NI or (M // NI) % 128 or n_out % groups:
+            return None
+        if self.ws_bytes and self.lib.pm_gemm_workspace_bytes(M, n_out, K, 0) > 0:
+            return None  # a split-K shape: its epilogue runs in the reduce pass, keep the separate statistics
+        return torch.empty((M // 128) * n_out * 2, dtype=torch.float32, device=self.device)
+
+    def _stats_end(self, out, col, stats):
+        if stats is None:
+            return out
+        NI, groups = stats
+        if col is None:
+            return out, self.groupnorm_stats(out, NI, groups)
+        M, n_out = out.shape
+        tot = torch.empty(NI, groups, 2, dtype=torch.float32, device=self.device)
+        rc = self.lib.pm_groupnorm_finalize_colstats(_ptr(col), _ptr(tot), M // 128, n_out, NI, groups, self._stream())
+        capi.check(rc, "pm_groupnorm_finalize_colstats")
+        return out, tot
+
     # -- GEMM family -----------------------------------------------------------------------------
-    def gemm(self, a, w, bias=None, residual=None, act="none", out=None, stream=False):
+    def gemm(self, a, w, bias=None, residual=None, act="none", out=None, stream=False, stats=None):
         """out[M, N] = epi(a[M, K] @ w[N, K]^T); GEGLU halves N (weights pre-interleaved)."""
         M, K = a.shape
         N = w.shape[0]
         assert w.shape[1] == K and w.is_contiguous() and w.dtype == self.dtype
         n_out = N // 2 if act == "geglu" else N
         flags, out = self._gemm_io(a, residual, out, M, n_out, stream)
+        col = self._stats_begin(M, n_out, stats, K)
         rc = self.lib.pm_gemm(_ptr(a), self._rows(a, True), _ptr(w), K, _ptr(bias),
                               _ptr(residual), residual.stride(0) if residual is not None else 0,
                               _ptr(out), out.stride(0), M, N, K, capi.ACT_CODES[act], flags, self.dt,
-                              _ptr(self.workspace), self.ws_bytes, self._stream())
+                              _ptr(self.workspace), self.ws_bytes, _ptr(col), self._stream())
         capi.check(rc, f"pm_gemm M={M} N={N} K={K}")
-        return out
+        return self._stats_end(out, col, stats)
 
     def conv3x3(self, x, wp, bias, F, H, W, stride=1, upsample=False, residual=None, out=None, stream=False,
-                pad_lo=1):
+                pad_lo=1, stats=None):
         """x [F*H*W, Cin] -> [F*Ho*Wo, Cout]; wp packed [Cout, 9*Cin]."""
         cin = x.shape[1]
         cout = wp.shape[0]
@@ -91,15 +118,17 @@ class HipOps:
         hv, wv = (2 * H, 2 * W) if upsample else (H, W)
         ho, wo = (hv + pad_lo - 2) // stride + 1, (wv + pad_lo - 2) // stride + 1
         flags, out = self._gemm_io(x, residual, out, F * ho * wo, cout, stream)
+        col = self._stats_begin(F * ho * wo, cout, stats, 9 * cin)
         rc = self.lib.pm_conv2d_3x3(_ptr(x), self._rows(x, True), _ptr(wp), _ptr(bias), _ptr(residual),
                                     residual.stride(0) if residual is not None else 0, _ptr(out),
                                     out.stride(0), F, H, W, cin, cout, stride, int(upsample), int(pad_lo),
                                     _ptr(self.zero_page), flags, self.dt, _ptr(self.workspace),
-                                    self.ws_bytes, self._stream())
+                                    self.ws_bytes, _ptr(col), self._stream())
         capi.check(rc, f"pm_conv2d_3x3 F={F} H={H} W={W} Cin={cin} Cout={cout}")
-        return out
+        return self._stats_end(out, col, stats)
 
-    def conv_t3(self, x, wp, bias, F, P, residual=None, halo_lo=None, halo_hi=None, out=None, stream=False):
+    def conv_t3(self, x, wp, bias, F, P, residual=None, halo_lo=None, halo_hi=None, out=None, stream=False,
+                stats=None):
         """3-tap conv over frames: x [F*P, Cin] -> [F*P, Cout]; wp packed [Cout, 3*Cin]."""
         cin = x.shape[1]
         cout = wp.shape[0]
@@ -107,14 +136,15 @@ class HipOps:
         for h in (halo_lo, halo_hi):
             assert h is None or (h.shape == (P, cin) and self._rows(h) == self._rows(x))
         flags, out = self._gemm_io(x, residual, out, F * P, cout, stream)
+        col = self._stats_begin(F * P, cout, stats, 3 * cin)
         rc = self.lib.pm_conv_temporal_k3(_ptr(x), self._rows(x, True), _ptr(halo_lo), _ptr(halo_hi),
                                           _ptr(wp), _ptr(bias), _ptr(residual),
                                           residual.stride(0) if residual is not None else 0,
                                           _ptr(out), out.stride(0), F, P, cin, cout,
                                           _ptr(self.zero_page), flags, self.dt, _ptr(self.workspace),
-                                    self.ws_bytes, self._stream())
+                                          self.ws_bytes, _ptr(col), self._stream())
         capi.check(rc, f"pm_conv_temporal_k3 F={F} P={P} Cin={cin} Cout={cout}")
-        return out
+        return self._stats_end(out, col, stats)
 
     def gemv(self, w, x, bias=None, silu_in=False, act="none"):
         """f32 y[N] = act(w[N, K] @ (silu?)(x[K]) + bias)."""
@@ -155,10 +185,11 @@ class HipOps:
         capi.check(rc, f"pm_groupnorm_apply NI={NI} P={P} C={C}")
         return out
 
-    def groupnorm(self, x, gamma, beta, eps, NI, silu, groups=32, stats_reduce=None, out=None):
+    def groupnorm(self, x, gamma, beta, eps, NI, silu, groups=32, stats_reduce=None, out=None, totals=None):
         """GroupNorm over NI instances of [P, C]; stats_reduce(totals [NI, groups, 2], local_count)
-        (frame-sharded mode) returns the all-rank totals and the total element count per group."""
-        tot = self.groupnorm_stats(x, NI, groups)
+        (frame-sharded mode) returns the all-rank totals and the total element count per group.
+        `totals`: statistics already produced by the op that wrote x (fused epilogue)."""
+        tot = totals if totals is not None else self.groupnorm_stats(x, NI, groups)
         count = None
         if stats_reduce is not None:
             tot, count = stats_reduce(tot, (x.shape[0] // NI) * (x.shape[1] // groups))

@@ -354,12 +354,13 @@ class UNetModel(nn.Module):
         return self
 
     # ---- graph ---------------------------------------------------------------------------------
-    def _gn(self, c, x, gb, eps, silu, per_frame):
+    def _gn(self, c, x, gb, eps, silu, per_frame, totals=None):
+        """`totals`: {sum, sumsq} already produced by the epilogue of the op that wrote x."""
         ops = c.ops
         if per_frame:
-            return ops.groupnorm(x, gb[0], gb[1], eps, c.F, silu)
+            return ops.groupnorm(x, gb[0], gb[1], eps, c.F, silu, totals=totals)
         red = c.fp.reduce_stats if c.fp is not None else None
-        return ops.groupnorm(x, gb[0], gb[1], eps, 1, silu, stats_reduce=red)
+        return ops.groupnorm(x, gb[0], gb[1], eps, 1, silu, stats_reduce=red, totals=totals)
 
     def _res_block(self, c, mod, x):
         ops, e = c.ops, c.w[self._names[mod]]
@@ -367,19 +368,24 @@ class UNetModel(nn.Module):
         h = self._gn(c, x, e["gn1"], 1e-5, True, True)
         lo, hi = e["emb_slice"]
         # conv outputs that only feed a GroupNorm stay f32 too (one rounding less per branch)
-        h = ops.conv3x3(h, e["conv1"], c.emb_bias[lo:hi], c.F, c.H, c.W, stream=True)
-        h = self._gn(c, h, e["gn2"], 1e-5, True, True)
+        # every conv whose output feeds a GroupNorm also emits that norm's statistics from its epilogue
+        h, tot = ops.conv3x3(h, e["conv1"], c.emb_bias[lo:hi], c.F, c.H, c.W, stream=True, stats=(c.F, 32))
+        h = self._gn(c, h, e["gn2"], 1e-5, True, True, totals=tot)
         skip = x if e["skip"] is None else ops.gemm(x, e["skip"][0], e["skip"][1], stream=True)
-        h = ops.conv3x3(h, e["conv2"][0], e["conv2"][1], c.F, c.H, c.W, residual=skip, stream=True)
-        if mod.use_temporal_conv:
-            ident = h
-            for i, (gb, wp, b) in enumerate(e["tconv"]):
-                t = self._gn(c, h, gb, 1e-5, True, False)
-                lo_h = hi_h = None
-                if c.fp is not None:
-                    lo_h, hi_h = c.fp.exchange_halo(t, P)
-                h = ops.conv_t3(t, wp, b, c.F, P, residual=ident if i == 3 else None, halo_lo=lo_h, halo_hi=hi_h,
-                                stream=True)
+        if not mod.use_temporal_conv:
+            return ops.conv3x3(h, e["conv2"][0], e["conv2"][1], c.F, c.H, c.W, residual=skip, stream=True)
+        h, tot = ops.conv3x3(h, e["conv2"][0], e["conv2"][1], c.F, c.H, c.W, residual=skip, stream=True,
+                             stats=(1, 32))
+        ident = h
+        for i, (gb, wp, b) in enumerate(e["tconv"]):
+            t = self._gn(c, h, gb, 1e-5, True, False, totals=tot)
+            lo_h = hi_h = None
+            if c.fp is not None:
+                lo_h, hi_h = c.fp.exchange_halo(t, P)
+            if i < 3:
+                h, tot = ops.conv_t3(t, wp, b, c.F, P, halo_lo=lo_h, halo_hi=hi_h, stream=True, stats=(1, 32))
+            else:
+                h = ops.conv_t3(t, wp, b, c.F, P, residual=ident, halo_lo=lo_h, halo_hi=hi_h, stream=True)
         return h
 
     def _block(self, c, e, h, mod, temporal, F, P, gather=False):

@@ -33,6 +33,14 @@ class TorchOps:
     def empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.dtype, device=self.device)
 
+    @staticmethod
+    def _with_stats(y, stats):
+        if stats is None:
+            return y
+        NI, groups = stats
+        yg = y.float().reshape(NI, y.shape[0] // NI, groups, -1)
+        return y, torch.stack([yg.sum((1, 3)), (yg * yg).sum((1, 3))], -1)
+
     def _out(self, t, out):
         t = t.to(self.dtype)
         if out is not None:
@@ -41,7 +49,7 @@ class TorchOps:
         return t
 
     # -- GEMM family -----------------------------------------------------------------------------
-    def gemm(self, a, w, bias=None, residual=None, act="none", out=None, stream=False):
+    def gemm(self, a, w, bias=None, residual=None, act="none", out=None, stream=False, stats=None):
         y = _f(a) @ _f(w).t()
         if bias is not None:
             y = y + _f(bias)
@@ -54,10 +62,10 @@ class TorchOps:
             y = (yy[:, :, 0] * F_.gelu(yy[:, :, 1])).reshape(y.shape[0], n // 2)
         if residual is not None:
             y = y + _f(residual)
-        return self._out(y, out)
+        return self._with_stats(self._out(y, out), stats)
 
     def conv3x3(self, x, wp, bias, F, H, W, stride=1, upsample=False, residual=None, out=None, stream=False,
-                pad_lo=1):
+                pad_lo=1, stats=None):
         cin, cout = x.shape[1], wp.shape[0]
         xi = _f(x).reshape(F, H, W, cin).permute(0, 3, 1, 2)
         if upsample:
@@ -68,9 +76,10 @@ class TorchOps:
         y = y.permute(0, 2, 3, 1).reshape(-1, cout)
         if residual is not None:
             y = y + _f(residual)
-        return self._out(y, out)
+        return self._with_stats(self._out(y, out), stats)
 
-    def conv_t3(self, x, wp, bias, F, P, residual=None, halo_lo=None, halo_hi=None, out=None, stream=False):
+    def conv_t3(self, x, wp, bias, F, P, residual=None, halo_lo=None, halo_hi=None, out=None, stream=False,
+                stats=None):
         cin, cout = x.shape[1], wp.shape[0]
         xi = _f(x).reshape(F, P, cin)
         lo = torch.zeros(1, P, cin) if halo_lo is None else _f(halo_lo).reshape(1, P, cin)
@@ -83,7 +92,7 @@ class TorchOps:
         y = y[0, :, :, :, 0].permute(1, 2, 0).reshape(F * P, cout)
         if residual is not None:
             y = y + _f(residual)
-        return self._out(y, out)
+        return self._with_stats(self._out(y, out), stats)
 
     def gemv(self, w, x, bias=None, silu_in=False, act="none"):
         xv = _f(x)
@@ -97,15 +106,22 @@ class TorchOps:
         return y
 
     # -- normalisation ---------------------------------------------------------------------------
-    def groupnorm(self, x, gamma, beta, eps, NI, silu, groups=32, stats_reduce=None, out=None):
+    def groupnorm(self, x, gamma, beta, eps, NI, silu, groups=32, stats_reduce=None, out=None, totals=None):
         M, C = x.shape
         P = M // NI
         xi = _f(x).reshape(NI, P, C).permute(0, 2, 1)  # [NI, C, P]
-        if stats_reduce is None:
+        if totals is not None and stats_reduce is None:  # statistics handed over by the producing op
+            cnt = P * (C // groups)
+            mean = totals[..., 0] / cnt
+            var = (totals[..., 1] / cnt - mean * mean).clamp_min(0)
+            xg = xi.reshape(NI, groups, -1)
+            y = ((xg - mean[..., None]) * torch.rsqrt(var + eps)[..., None]).reshape(NI, C, P)
+            y = y * _f(gamma)[None, :, None] + _f(beta)[None, :, None]
+        elif stats_reduce is None:
             y = F_.group_norm(xi, groups, _f(gamma), _f(beta), eps)
         else:
             xg = xi.reshape(NI, groups, -1)
-            part = torch.stack([xg.sum(-1), (xg * xg).sum(-1)], -1)  # [NI, groups, 2]
+            part = totals if totals is not None else torch.stack([xg.sum(-1), (xg * xg).sum(-1)], -1)
             tot, count = stats_reduce(part, P * (C // groups))
             mean = tot[..., 0] / count
             var = (tot[..., 1] / count - mean * mean).clamp_min(0)

@@ -482,3 +482,35 @@ def test_conv3x3_asymmetric_pad_stride2(hip_ops_factory, dtype):
         want = torch.nn.functional.conv2d(xi, w.float(), bias, stride=2).permute(0, 2, 3, 1).reshape(-1, Cout)
         got = ops.conv3x3(x.cuda(), packing.pack_conv3x3(w).cuda(), bias.cuda(), F, H, W, stride=2, pad_lo=0)
         assert got.shape == want.shape and rel_err(got, want) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fused_groupnorm_statistics(hip_ops_factory, dtype):
+    """`stats=(NI, groups)`: the epilogue's column sums -> GroupNorm totals equal a statistics pass over
+    the stored output (per-frame and (T,H,W); conv, temporal conv, GEMM; ragged instance -> fallback)."""
+    ops = hip_ops_factory(dtype)
+    F, H, W, Cin, Cout = 4, 16, 16, 64, 320            # 256 rows per frame = 2 row tiles
+    x = rnd(F * H * W, Cin, dtype=dtype, seed=1)
+    wp = rnd(Cout, 9 * Cin, dtype=dtype, scale=(9 * Cin) ** -0.5, seed=2)
+    b = rnd(Cout, dtype=torch.float32, seed=3)
+    res = rnd(F * H * W, Cout, dtype=torch.float32, seed=4)
+    for NI in (F, 1):
+        out, tot = ops.conv3x3(x.cuda(), wp.cuda(), b.cuda(), F, H, W, residual=res.cuda(), stream=True, stats=(NI, 32))
+        want_out, want_tot = REF.conv3x3(x, wp, b, F, H, W, residual=res, stats=(NI, 32))
+        assert rel_err(out, want_out) <= 2e-5 and tot.shape == (NI, 32, 2)
+        assert rel_err(tot, want_tot) <= 1e-4
+        assert rel_err(tot, ops.groupnorm_stats(out, NI)) <= 2e-6   # == the unfused statistics pass
+        gamma = 1 + 0.2 * rnd(Cout, dtype=torch.float32, seed=5)
+        beta = 0.3 * rnd(Cout, dtype=torch.float32, seed=6)
+        y = ops.groupnorm(out, gamma.cuda(), beta.cuda(), 1e-5, NI, True, totals=tot)
+        assert rel_err(y, REF.groupnorm(want_out, gamma, beta, 1e-5, NI, True)) <= TOL[dtype]
+    xt = rnd(4 * 128, 128, dtype=dtype, seed=7)
+    wt = rnd(128, 3 * 128, dtype=dtype, scale=384 ** -0.5, seed=8)
+    out, tot = ops.conv_t3(xt.cuda(), wt.cuda(), None, 4, 128, stream=True, stats=(1, 32))
+    assert rel_err(tot, ops.groupnorm_stats(out, 1)) <= 2e-6
+    out, tot = ops.gemm(xt.cuda(), wt[:, :128].contiguous().cuda(), stats=(4, 32))  # 16-bit output:
+    assert rel_err(tot, ops.groupnorm_stats(out, 4)) <= 1e-3  # totals are of the f32 values before rounding
+    # 100 rows per instance: not a whole number of 128-row tiles -> ordinary statistics pass
+    xr = rnd(3 * 100, 64, dtype=dtype, seed=9)
+    out, tot = ops.gemm(xr.cuda(), rnd(64, 64, dtype=dtype, seed=10).cuda(), stats=(3, 32))
+    assert tot.shape == (3, 32, 2) and rel_err(tot, ops.groupnorm_stats(out, 3)) <= 1e-6
