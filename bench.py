@@ -59,10 +59,16 @@ def cpu_baseline(pm, res, ins, cond):
     sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
     x = torch.cat([ins["x_T"], ins["c_concat"]], 1).float().cpu()
     ctx = cond["c_crossattn"][0].float().cpu()
+    # eager PyTorch on many small ops scales negatively past ~16 threads (measured on the GPU box's
+    # 2 x 64-core EPYC: 16 threads 3.8 s, 32: 5.2 s, 64: 11.6 s, 128: 25.7 s for the same forward)
+    prev = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 16))
     t0 = time.time()
     unet_ref.unet_forward(sd, x, torch.tensor([500]), ctx, torch.tensor([15]))
     dt = time.time() - t0
-    return {"value": 1.0 / (2.0 * dt), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+    used = torch.get_num_threads()
+    torch.set_num_threads(prev)
+    return {"value": 1.0 / (2.0 * dt), "unit": "steps/s", "cores": used, "kind": "port",
             "sample": f"1 of the 2 U-Net forwards of one CFG DDIM step at {res} (f32 oracle, {dt:.1f} s), x2 per step"}
 
 
@@ -203,7 +209,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel<A_CONV3X3> (pm_conv2d_3x3)",
                          "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "launches": n, "avg_launch_ms": ms / n,
-                         "share_of_step_time": (ms * 1e-3) / elapsed},
+                         "share_of_step_time": (ms * 1e-3 / 2.0) / (elapsed / a.steps)},
         }
         if a.cpu_baseline == "auto" and world == 1:
             out["cpu_baseline"] = cpu_baseline(pm, a.res, ins, {"c_crossattn": [ins["c_crossattn"]]})
