@@ -1,0 +1,42 @@
+"""CPU: the reference's checkpoint wire formats (Lightning state_dict, DeepSpeed module shard with the
+`_forward_module.` prefix, Open-Pandora pytorch_model.bin, the 256-model `framestride_embed` rename)
+load into the drop-in U-Net / AutoencoderKL (inference.py:27-52, tools/ckpt2bin.py:14, model.py:599)."""
+import torch
+
+from open_pandora_amd import checkpoint, synth
+from open_pandora_amd.autoencoder import DDCONFIG, AutoencoderKL
+from open_pandora_amd.unet import UNetModel
+from test_oracle_golden import RH_KW
+
+
+def _models():
+    unet = UNetModel(**dict(RH_KW, model_channels=64))
+    ae = AutoencoderKL(ddconfig=dict(DDCONFIG, ch=32))
+    return unet, ae
+
+
+def test_wire_formats_round_trip():
+    unet, ae = _models()
+    usd = synth.synth_state_dict(unet, seed=1)
+    asd = synth.synth_state_dict(ae, seed=2)
+    lightning = {"state_dict": {**{"model.diffusion_model." + k: v for k, v in usd.items()},
+                                **{"first_stage_model." + k: v for k, v in asd.items()},
+                                "cond_stage_model.dummy": torch.zeros(1), "scale_arr": torch.zeros(3)}}
+    deepspeed = {"module": {"_forward_module." + k: v for k, v in lightning["state_dict"].items()}}
+    pandora = {**{"diffusion_model.model.diffusion_model." + k: v for k, v in usd.items()},
+               **{"diffusion_model.first_stage_model." + k: v for k, v in asd.items()},
+               "video_model.lm_head.weight": torch.zeros(2, 2)}
+    legacy = {"state_dict": {"model.diffusion_model." + k.replace("fps_embedding", "framestride_embed"): v
+                             for k, v in usd.items()}}
+    for blob in (lightning, deepspeed, pandora, legacy, usd):
+        u2, _ = _models()
+        res = checkpoint.load_unet(u2, blob)
+        assert not res.missing_keys and not res.unexpected_keys
+        assert all(torch.equal(u2.state_dict()[k], usd[k]) for k in usd)
+    for blob in (lightning, deepspeed, pandora, asd):
+        _, a2 = _models()
+        res = checkpoint.load_autoencoder(a2, blob)
+        assert not res.missing_keys and not res.unexpected_keys
+        assert all(torch.equal(a2.state_dict()[k], asd[k]) for k in asd)
+    parts = checkpoint.split_checkpoint(pandora)
+    assert list(parts["rest"]) == ["video_model.lm_head.weight"]
