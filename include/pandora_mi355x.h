@@ -69,10 +69,10 @@ int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float*
             float* colstats, void* stream);
 
 /* Fused GroupNorm statistics.  When `colstats` is not NULL the GEMM-family epilogue also writes, per
- * 128-row output tile and output column, {sum, sum of squares} of exactly the values it stores:
- * colstats [ceil(M/128)][Nout][2] f32 (the call then runs unsplit).  pm_groupnorm_finalize_colstats turns
- * them into GroupNorm totals [NI][groups][2] for NI instances of mtiles/NI consecutive row tiles each
- * (per-frame statistics: rows per frame % 128 == 0; (T,H,W): NI = 1), replacing pm_groupnorm_stats' read
+ * block of 64 output rows and output column, {sum, sum of squares} of exactly the values it stores:
+ * colstats [ceil(M/64)][Nout][2] f32 (the call then runs unsplit).  pm_groupnorm_finalize_colstats turns
+ * them into GroupNorm totals [NI][groups][2] for NI instances of mtiles/NI consecutive row blocks each
+ * (mtiles = ceil(M/64); per-frame statistics: rows per frame % 64 == 0; (T,H,W): NI = 1), replacing pm_groupnorm_stats' read
  * pass over the tensor for the GroupNorm that follows a conv (openaimodel3d.py:178-183,258-269). */
 int pm_groupnorm_finalize_colstats(const float* colstats, float* totals, int64_t mtiles, int64_t C,
                                    int64_t NI, int groups, void* stream);

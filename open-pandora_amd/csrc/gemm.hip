@@ -34,7 +34,7 @@ struct GemmParams {
   int ntiles, mtiles;
   int splits, ktps;  // split-K: number of K slices and K-tiles per slice
   float* ws;         // split-K partial slabs [splits][M][N] f32
-  float* colstats;   // optional [mtiles][Nout][2]: per-row-tile column {sum, sum of squares} of the output
+  float* colstats;   // optional [ceil(M/64)][Nout][2]: column {sum, sum of squares} of every 64 output rows
   // conv3x3
   int Hin, Win, Hv, Wv, Cin, Ho, Wo, stride, ups, pad;  // pad: zero rows/cols before the image (1, or 0)
   // temporal conv
@@ -42,6 +42,9 @@ struct GemmParams {
   const void* halo_lo;
   const void* halo_hi;
   const void* zero;
+#ifdef PM_RING_PROF
+  long long* prof;  // [grid][8 waves][4] cycle sums (tools/ring_prof.py)
+#endif
 };
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -454,29 +457,471 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const GemmPara
       }
     }
     __syncthreads();
-  }
-  if (want_stats) {  // reduce the rpp row-lanes of every column in a fixed order (deterministic)
-    float* red = stage;  // [rpp][tw][2]
+    if (want_stats) {  // column sums of these 64 rows: fixed-order sum over the rpp row-lanes (deterministic)
+      float* red = stage;  // [rpp][tw][2]
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      red[((srow * tw) + scol * 8 + e) * 2] = cs[e];
-      red[((srow * tw) + scol * 8 + e) * 2 + 1] = cq[e];
-    }
-    __syncthreads();
-    if (tid < tw) {
-      float a = 0.f, b = 0.f;
-      for (int r = 0; r < rpp; ++r) {
-        a += red[(r * tw + tid) * 2];
-        b += red[(r * tw + tid) * 2 + 1];
+      for (int e = 0; e < 8; ++e) {
+        red[((srow * tw) + scol * 8 + e) * 2] = cs[e];
+        red[((srow * tw) + scol * 8 + e) * 2 + 1] = cq[e];
+        cs[e] = cq[e] = 0.f;
       }
-      const int n = nbase + tid;
-      if (n < nout) {
-        float* dst = p.colstats + ((int64_t)mt * nout + n) * 2;
-        dst[0] = a;
-        dst[1] = b;
+      __syncthreads();
+      if (tid < tw) {
+        float a = 0.f, b = 0.f;
+        for (int r = 0; r < rpp; ++r) {
+          a += red[(r * tw + tid) * 2];
+          b += red[(r * tw + tid) * 2 + 1];
+        }
+        const int n = nbase + tid;
+        if (n < nout && (mt * WMW + half) * 64 < p.M) {  // (a ragged last tile has no second block)
+          float* dst = p.colstats + (((int64_t)mt * WMW + half) * nout + n) * 2;
+          dst[0] = a;
+          dst[1] = b;
+        }
       }
+      __syncthreads();
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ring-pipelined, wave-specialised persistent variant (16-bit operands, whole K-tiles: dense, fast 3x3
+// and temporal modes).
+//
+// The 2-stage kernel above issues its DMAs from the waves that also issue the MFMAs: a wave's
+// instructions issue in order, so whenever the CU's load path is backed up the MFMAs wait behind the
+// stalled global_load_lds, and with one workgroup per CU (every grid of <= 256 tiles: the M = 2560 / 640
+// levels) a K-step costs a full round trip (~1.3 us measured: 25 GB/s per CU against the ~68 GB/s a CU
+// can ingest).  Here one 8-wave workgroup owns the CU:
+//   * waves 4-7 only load: 4 LDS stages of 32 KiB form a ring with the DMA of three K-tiles (96 KiB) in
+//     flight across the barrier (counted s_waitcnt vmcnt, never 0 in steady state);
+//   * waves 0-3 only compute (ds_read_b128 + MFMA, 64x64 per wave) and run the epilogue;
+//   * one raw s_barrier per K-step hands stage k to the consumers and stage k-1 back to the loaders;
+//   * the workgroup is persistent: it walks its share of the (tile, split) list and the loader cursor
+//     runs three K-steps ahead ACROSS tile boundaries, so the next tile streams in during the epilogue;
+//   * the epilogue is wave-private (8 KiB of xor-swizzled f32 scratch per consumer wave, no barrier):
+//     each wave stores its own 64x64 quadrant in whole 256-byte row segments.
+// LDS: 128 KiB ring + 32 KiB scratch = the CU's whole 160 KiB.
+constexpr int RING_STAGES = 4;
+constexpr int RING_LDS = RING_STAGES * 2 * TILE_BYTES + 4 * 32 * 64 * 4;
+
+template <typename T, int AMODE>
+__global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
+  static_assert(AMODE != A_CONV3X3, "K tails / nearest-x2 stay on gemm_kernel");
+  constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const As = smem;
+  char* const Bs = smem + TILE_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int G = gridDim.x;
+  const int nwork = p.mtiles * p.ntiles * p.splits;
+  const int slot_id = xcd_remap(blockIdx.x, G);  // round i of this workgroup: work item i * G + slot_id
+  const int nk_all = p.K / BK;
+
+  // work item -> (row tile, column tile, K slice), same supertile order as gemm_kernel
+  auto decode = [&](int w, int& mt, int& nt, int& split) {
+    constexpr int GM = 8;
+    split = w % p.splits;
+    const int wg = w / p.splits;
+    const int grp = wg / (GM * p.ntiles);
+    const int first_m = grp * GM;
+    const int gm = (p.mtiles - first_m < GM) ? p.mtiles - first_m : GM;
+    const int rin = wg - grp * GM * p.ntiles;
+    nt = rin / gm;
+    mt = first_m + (rin - nt * gm);
+  };
+
+  if (wave >= 4) {
+    // ================= loader waves (see gemm_kernel for the source-side swizzle / scalarised K walk) =====
+    const int lw = wave - 4;
+    const int r8 = lane >> 3;             // row inside an 8-row DMA piece; tile row = 32*j + 8*lw + r8
+    const int lc = (lane & 7) ^ r8;       // logical 16-byte k-chunk this lane fetches ((row & 7) == r8)
+    const char* const Ab = reinterpret_cast<const char*>(p.A);
+    const char* const Wb = reinterpret_cast<const char*>(p.Wt);
+    const char* const zero = reinterpret_cast<const char*>(p.zero);
+    uint32_t b_off[4], a_off[4];
+    int a_y[4], a_x[4];
+    int tap_s = 0, ch_s = 0;
+    int l_round = 0, l_kt = 0, l_kt1 = 0;
+    auto loader_begin = [&]() -> bool {
+      const int w = l_round * G + slot_id;
+      if (w >= nwork) return false;
+      int mt, nt, split;
+      decode(w, mt, nt, split);
+      const int m0 = mt * BM, n0 = nt * BN;
+      l_kt = split * p.ktps;
+      l_kt1 = (l_kt + p.ktps < nk_all) ? l_kt + p.ktps : nk_all;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int n = n0 + 32 * j + 8 * lw + r8;
+        if (n > p.N - 1) n = p.N - 1;
+        b_off[j] = (uint32_t)(((int64_t)n * p.ldw + lc * 8) * 2);
+        int m = m0 + 32 * j + 8 * lw + r8;
+        if (m > p.M - 1) m = p.M - 1;
+        if (AMODE == A_DENSE) {
+          a_off[j] = (uint32_t)(((int64_t)m * p.lda + lc * 8) * 2);
+          a_y[j] = a_x[j] = 0;
+        } else if (AMODE == A_CONV3X3_FAST) {
+          const int hw = p.Ho * p.Wo;
+          const int f = m / hw;
+          const int rem = m - f * hw;
+          const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+          a_y[j] = oy * p.stride + 1 - p.pad;
+          a_x[j] = ox * p.stride + 1 - p.pad;
+          a_off[j] = (uint32_t)((((int64_t)f * p.Hin + a_y[j]) * p.Win + a_x[j]) * p.lda * 2 + lc * 16);
+        } else {
+          const int f = m / p.P;
+          const int pix = m - f * p.P;
+          a_off[j] = (uint32_t)((((int64_t)f * p.P + pix) * p.lda + lc * 8) * 2);
+          a_y[j] = f;
+          a_x[j] = pix;
+        }
+      }
+      if (AMODE != A_DENSE) {
+        tap_s = (l_kt * BK) / p.Cin;
+        ch_s = l_kt * BK - tap_s * p.Cin;
+      }
+      return true;
+    };
+    auto load_tile = [&](int kt, int buf) {
+      const char* wb = Wb + (int64_t)kt * (BK * 2);
+      const char* ab = Ab;
+      int dy = 0, dx = 0;
+      if (AMODE == A_DENSE) {
+        ab = Ab + (int64_t)kt * (BK * 2);
+      } else if (AMODE == A_CONV3X3_FAST) {
+        dy = tap_s / 3;
+        dx = tap_s - dy * 3;
+        ab = Ab + ((int64_t)((dy - 1) * p.Win + (dx - 1)) * p.lda + ch_s) * 2;
+      } else {
+        ab = Ab + ((int64_t)(tap_s - 1) * p.P * p.lda + ch_s) * 2;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const char* src;
+        if (AMODE == A_DENSE) {
+          src = ab + a_off[j];
+        } else if (AMODE == A_CONV3X3_FAST) {
+          const bool ok = (unsigned)(a_y[j] + dy - 1) < (unsigned)p.Hv && (unsigned)(a_x[j] + dx - 1) < (unsigned)p.Wv;
+          src = ok ? ab + a_off[j] : zero;
+        } else {
+          const int sf = a_y[j] + tap_s - 1;
+          if (sf < 0)
+            src = p.halo_lo ? reinterpret_cast<const char*>(p.halo_lo) + ((int64_t)a_x[j] * p.lda + ch_s + lc * 8) * 2 : zero;
+          else if (sf >= p.F)
+            src = p.halo_hi ? reinterpret_cast<const char*>(p.halo_hi) + ((int64_t)a_x[j] * p.lda + ch_s + lc * 8) * 2 : zero;
+          else
+            src = ab + a_off[j];
+        }
+        const int dst = buf * STAGE_BYTES + (32 * j + 8 * lw) * 128;
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(As + dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void*)(wb + b_off[j]), (lds_void*)(Bs + dst), 16, 0, 0);
+      }
+      if (AMODE != A_DENSE) {
+        ch_s += BK;
+        if (ch_s >= p.Cin) {
+          ch_s -= p.Cin;
+          ++tap_s;
+        }
+      }
+    };
+    bool l_valid = loader_begin();
+    int l_stage = 0, inflight = 0;
+    auto issue = [&]() {
+      if (!l_valid) return;
+      load_tile(l_kt, l_stage);
+      l_stage = (l_stage + 1) & (RING_STAGES - 1);
+      ++inflight;
+      if (++l_kt == l_kt1) {
+        ++l_round;
+        l_valid = loader_begin();
+      }
+    };
+    issue();
+    issue();
+    issue();
+#ifdef PM_RING_PROF
+    long long t_wait = 0, t_bar = 0, t_issue = 0, t_n = 0;
+#endif
+    // one iteration per K-step q of the consumers.  Barrier q publishes stages q AND q+1 (the consumers
+    // pre-read the first fragments of step q+1 during step q), so everything but the youngest K-tile (8
+    // DMAs per loader wave) must have landed; it also proves the consumers are done with stage q-1, which
+    // the issue right behind it overwrites with step q+3.
+    while (inflight > 0) {
+#ifdef PM_RING_PROF
+      const long long c0 = clock64();
+#endif
+      if (inflight >= 3)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef PM_RING_PROF
+      const long long c1 = clock64();
+#endif
+      __builtin_amdgcn_s_barrier();
+#ifdef PM_RING_PROF
+      const long long c2 = clock64();
+#endif
+      issue();
+      --inflight;
+#ifdef PM_RING_PROF
+      const long long c3 = clock64();
+      t_wait += c1 - c0; t_bar += c2 - c1; t_issue += c3 - c2; ++t_n;
+#endif
+    }
+#ifdef PM_RING_PROF
+    if (p.prof && lane == 0) {
+      long long* d = p.prof + ((long long)blockIdx.x * 8 + wave) * 4;
+      d[0] = t_wait; d[1] = t_bar; d[2] = t_issue; d[3] = t_n;
+    }
+#endif
+    return;
+  }
+
+  // ================= consumer waves =================
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  float* const scr = reinterpret_cast<float*>(smem + RING_STAGES * STAGE_BYTES) + wave * (32 * 64);  // [32][64] f32
+  const int a_frag = (wm * 64 + fr) * 128, b_frag = (wn * 64 + fr) * 128;
+  const int slot0 = ((fq) ^ (fr & 7)) << 4, slot1 = ((4 + fq) ^ (fr & 7)) << 4;
+  const bool partial = p.splits > 1;
+  int c_stage = 0;
+#ifdef PM_RING_PROF
+  long long t_cbar = 0, t_comp = 0, t_epi = 0, t_cn = 0;
+#endif
+
+  // Fragment registers are double-buffered by k-substep: set 0 (k 0..31 of a stage) is read while the
+  // MFMAs of the previous substep run - across the barrier for the first substep of the next stage - so
+  // no MFMA ever waits for LDS latency (one consumer wave per SIMD: nobody else would hide it).
+  Pack8<T> fa0[4], fb0[4], fa1[4], fb1[4];
+  auto read_frags = [&](Pack8<T>* fa, Pack8<T>* fb, int stg, int slot) {
+    const char* as = As + stg * STAGE_BYTES + a_frag + slot;
+    const char* bs = Bs + stg * STAGE_BYTES + b_frag + slot;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i].u = *reinterpret_cast<const u32x4*>(as + i * 2048);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[j].u = *reinterpret_cast<const u32x4*>(bs + j * 2048);
+  };
+  __builtin_amdgcn_s_barrier();  // barrier 0: stages 0 and 1 are in LDS
+  read_frags(fa0, fb0, 0, slot0);
+
+  for (int c_round = 0;; ++c_round) {
+    const int w = c_round * G + slot_id;
+    if (w >= nwork) break;
+    const bool last_tile = (w + G >= nwork);
+    int mt, nt, split;
+    decode(w, mt, nt, split);
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int kt0 = split * p.ktps;
+    const int kt1 = (kt0 + p.ktps < nk_all) ? kt0 + p.ktps : nk_all;
+    // the bias of this wave's columns: requested now, needed in the epilogue
+    const float* bias_p = partial ? nullptr : p.bias;
+    float bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fr;
+      bv[j] = (bias_p != nullptr && n < p.N) ? bias_p[n] : 0.f;
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = kt0; kt < kt1; ++kt) {
+#ifdef PM_RING_PROF
+      const long long c0 = clock64();
+#endif
+      const bool more = (kt + 1 < kt1) || !last_tile;  // does a next step exist (possibly the next tile's)?
+      const int nstage = (c_stage + 1) & (RING_STAGES - 1);
+      // Issue pattern pinned per substep: one ds_read_b128 behind each of the first 8 MFMAs (an MFMA holds
+      // the SIMD's issue for 8 of its 16 cycles: the read rides in the gap), then 8 bare MFMAs that cover
+      // the last read's latency.  Left alone, hipcc sinks each read group down to its first use (the MFMAs
+      // then wait out the LDS latency); read groups issued en bloc between the MFMA groups cost ~100
+      // issue cycles each (in-kernel stamps: 726 cycles per K-step against 512 of MFMA).
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(fa1, fb1, c_stage, slot1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fa0[i].v, fb0[j].v, acc[i][j]);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // next step's first fragments: that stage was published by the previous step's barrier.  Read
+      // unconditionally (after the very last step the values are simply unused): a branch here would make
+      // hipcc merge the LDS wait counts of both paths and stall the MFMAs on these reads
+      read_frags(fa0, fb0, nstage, slot0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fa1[i].v, fb1[j].v, acc[i][j]);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef PM_RING_PROF
+      const long long c1 = clock64();
+#endif
+      // all reads of stage c_stage have returned (their MFMAs are issued): hand it back, get stage + 2
+      if (more) __builtin_amdgcn_s_barrier();
+      c_stage = nstage;
+#ifdef PM_RING_PROF
+      const long long c2 = clock64();
+      t_comp += c1 - c0; t_cbar += c2 - c1; ++t_cn;
+#endif
+    }
+#ifdef PM_RING_PROF
+    const long long e0 = clock64();
+#endif
+
+    // ---------------- epilogue of this wave's 64x64 quadrant (the loaders keep streaming the next tile) ----
+    const int act = partial ? PM_ACT_NONE : p.act;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] += bv[j];
+    const bool geglu = (act == PM_ACT_GEGLU);
+    if (act == PM_ACT_SILU) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = silu_f(acc[i][j][r]);
+    } else if (geglu) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][jj][r] = acc[i][2 * jj][r] * gelu_erf_f(acc[i][2 * jj + 1][r]);
+    }
+    const int wcols = geglu ? 32 : 64;        // output columns of this wave
+    const int nblk = geglu ? 2 : 4;
+    const int nout = geglu ? (p.N >> 1) : p.N;
+    const int ncol0 = (geglu ? (n0 >> 1) : n0) + wn * wcols;
+    T* __restrict__ Cg = reinterpret_cast<T*>(p.C);
+    const T* __restrict__ Rg = (partial || p.res32) ? nullptr : reinterpret_cast<const T*>(p.R);
+    float* __restrict__ Cf = partial ? p.ws + (int64_t)split * p.M * p.N : reinterpret_cast<float*>(p.C);
+    const float* __restrict__ Rf = (partial || !p.res32) ? nullptr : reinterpret_cast<const float*>(p.R);
+    const bool out32 = partial || p.out32 != 0;
+    const int64_t ldc = partial ? p.N : p.ldc;
+    // store pass: a lane owns 4 consecutive columns; 16 (8: GEGLU) lanes cover a row of the quadrant, so a
+    // wave instruction reads 4 (8) whole scratch rows and stores 4 (8) whole row segments
+    const int lpr = wcols >> 2;
+    const int rpi = 64 / lpr;
+    const int lcol = (lane % lpr) * 4, lrow = lane / lpr;
+    const bool want_stats = (p.colstats != nullptr) && !partial;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+    const int n = ncol0 + lcol;
+
+#pragma unroll
+    for (int chunk = 0; chunk < 2; ++chunk) {
+      // scratch row = il*16 + 4*fq + r: the 16-column block index is xor-ed with (row >> 2) & 3 == fq, so
+      // the fq groups of a ds_write_b32 land on different banks without row padding
+#pragma unroll
+      for (int il = 0; il < 2; ++il)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (j < nblk) scr[(il * 16 + 4 * fq + r) * 64 + ((j * 16 + fr) ^ (fq << 4))] = acc[chunk * 2 + il][j][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private scratch: LDS ops of one wave are in order
+      for (int rr = lrow; rr < 32; rr += rpi) {
+        const int m = m0 + wm * 64 + chunk * 32 + rr;
+        if (m < p.M && n < nout) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(scr + rr * 64 + (lcol ^ (((rr >> 2) & 3) << 4)));
+          float v[4] = {v0[0], v0[1], v0[2], v0[3]};
+          const bool fullr = (n + 4 <= nout);
+          if (Rf != nullptr) {
+            const float* rptr = Rf + (int64_t)m * p.ldr + n;
+            if (fullr && ((p.ldr & 3) == 0)) {
+              const f32x4 r0 = *reinterpret_cast<const f32x4*>(rptr);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += r0[e];
+            } else {
+              for (int e = 0; e < 4 && n + e < nout; ++e) v[e] += rptr[e];
+            }
+          } else if (Rg != nullptr) {
+            const T* rptr = Rg + (int64_t)m * p.ldr + n;
+            if (fullr && ((p.ldr & 3) == 0)) {
+              Pack4<T> rv;
+              rv.u = *reinterpret_cast<const u32x2*>(rptr);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += to_f32(rv.e[e]);
+            } else {
+              for (int e = 0; e < 4 && n + e < nout; ++e) v[e] += to_f32(rptr[e]);
+            }
+          }
+          if (want_stats) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n + e < nout) {
+                cs[e] += v[e];
+                cq[e] = fmaf(v[e], v[e], cq[e]);
+              }
+          }
+          if (out32) {
+            float* cptr = Cf + (int64_t)m * ldc + n;
+            if (fullr && ((ldc & 3) == 0))
+              *reinterpret_cast<f32x4*>(cptr) = f32x4{v[0], v[1], v[2], v[3]};
+            else
+              for (int e = 0; e < 4 && n + e < nout; ++e) cptr[e] = v[e];
+          } else {
+            T* cptr = Cg + (int64_t)m * ldc + n;
+            if (fullr && ((ldc & 3) == 0)) {
+              Pack4<T> ov;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) ov.e[e] = from_f32<T>(v[e]);
+              *reinterpret_cast<u32x2*>(cptr) = ov.u;
+            } else {
+              for (int e = 0; e < 4 && n + e < nout; ++e) cptr[e] = from_f32<T>(v[e]);
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (want_stats) {  // column sums of this wave's 64 rows: fixed xor tree over the row-lanes (deterministic)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        for (int o = 32; o >= lpr; o >>= 1) {
+          cs[e] += __shfl_xor(cs[e], o, 64);
+          cq[e] += __shfl_xor(cq[e], o, 64);
+        }
+      }
+      if (lane < lpr && (mt * 2 + wm) * 64 < p.M) {  // (a ragged last tile has no second block)
+        float* dst = p.colstats + (((int64_t)mt * 2 + wm) * nout + n) * 2;
+        for (int e = 0; e < 4 && n + e < nout; ++e) {
+          dst[2 * e] = cs[e];
+          dst[2 * e + 1] = cq[e];
+        }
+      }
+    }
+#ifdef PM_RING_PROF
+    t_epi += clock64() - e0;
+#endif
+  }
+#ifdef PM_RING_PROF
+  if (p.prof && lane == 0) {
+    long long* d = p.prof + ((long long)blockIdx.x * 8 + wave) * 4;
+    d[0] = t_cbar; d[1] = t_comp; d[2] = t_epi; d[3] = t_cn;
+  }
+#endif
 }
 
 // split-K second pass: out = epi(sum_s ws[s]) ; one thread per 4 consecutive columns
@@ -513,6 +958,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
   }
 }
 
+static int g_ring = 1;  // PANDORA_GEMM_RING: 0 = never, 1 = where the grid is at most g_ring_max_work, 2 = always
+static int g_ring_max_work = 256;  // one round: at most one tile per CU (measured: the 2-stage kernel wins once CUs hold 2 tiles)
+static int g_num_cus = 0;
+#ifdef PM_RING_PROF
+static long long* g_ring_prof = nullptr;
+#endif
 static bool g_allow_big = false;  // PANDORA_GEMM_BIG=1 enables the 256x128 tile (measured: no gain yet)
 static int g_split_min_nk = 24;     // PANDORA_SPLITK_MIN_NK: shortest K loop (in 64-wide tiles) that is split
 
@@ -535,6 +986,10 @@ static void plan_split(GemmParams& p, void* workspace, size_t workspace_bytes) {
     g_allow_big = (e && e[0] == '1');
     const char* m = getenv("PANDORA_SPLITK_MIN_NK");
     if (m) g_split_min_nk = atoi(m);
+    const char* r = getenv("PANDORA_GEMM_RING");
+    if (r) g_ring = atoi(r);
+    const char* rw = getenv("PANDORA_GEMM_RING_MAX_WORK");
+    if (rw) g_ring_max_work = atoi(rw);
     return true;
   }();
   (void)init;
@@ -576,8 +1031,42 @@ template <typename T, int AMODE, bool A32, bool BIG> static int launch1(const Ge
   return check_launch();
 }
 
+template <typename T, int AMODE> static int launch_ring(const GemmParams& p, hipStream_t stream) {
+  if (g_num_cus == 0) {
+    int dev = 0, n = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    g_num_cus = n;
+  }
+  GemmParams q = p;
+#ifdef PM_RING_PROF
+  q.prof = g_ring_prof;
+#endif
+  q.mtiles = (p.M + BM - 1) / BM;
+  const int64_t nwork = (int64_t)q.mtiles * p.ntiles * p.splits;
+  const int grid = (int)(nwork < g_num_cus ? nwork : g_num_cus);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<T, AMODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_ring_kernel<T, AMODE>), dim3(grid), dim3(512), RING_LDS, stream, q);
+  if (p.splits > 1) {
+    const int64_t work = (int64_t)p.M * ((p.N + 3) / 4);
+    int64_t nb = (work + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)nb), dim3(256), 0, stream, p);
+  }
+  return check_launch();
+}
+
 template <typename T, int AMODE> static int launch(const GemmParams& p, int flags, hipStream_t stream) {
   if (flags & PM_FLAG_A_F32) return launch1<T, AMODE, true, false>(p, stream);
+  if constexpr (AMODE != A_CONV3X3) {
+    const int64_t nwork = (int64_t)((p.M + BM - 1) / BM) * p.ntiles * p.splits;
+    if (g_ring == 2 || (g_ring == 1 && nwork <= g_ring_max_work)) return launch_ring<T, AMODE>(p, stream);
+  }
   // big tile when it still yields at least one workgroup per CU (and no split-K, no K tail)
   const int64_t big_tiles = (int64_t)((p.M + 255) / 256) * p.ntiles;
   if (AMODE != A_CONV3X3 && p.splits == 1 && big_tiles >= 256 && g_allow_big) return launch1<T, AMODE, false, true>(p, stream);
@@ -685,6 +1174,10 @@ extern "C" int pm_conv_temporal_k3(const void* x, int64_t ldx, const void* halo_
   plan_split(p, workspace, workspace_bytes);
   PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_CONVT3>(p, flags, (hipStream_t)stream)));
 }
+
+#ifdef PM_RING_PROF
+extern "C" void pm_debug_ring_prof(void* buf) { g_ring_prof = reinterpret_cast<long long*>(buf); }
+#endif
 
 extern "C" size_t pm_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int act) {
   int ktps;

@@ -70,16 +70,16 @@ class HipOps:
     # fused GroupNorm statistics: `stats=(NI, groups)` on a GEMM-family op returns (out, totals) where
     # totals [NI, groups, 2] are the {sum, sumsq} of the stored output per instance (NI consecutive row
     # blocks) and group; taken from the epilogue's column sums when every instance is a whole number of
-    # 128-row tiles, else by the ordinary statistics pass over the output.
+    # 64-row blocks, else by the ordinary statistics pass over the output.
     def _stats_begin(self, M, n_out, stats, K=0):
         if stats is None:
             return None
         NI, groups = stats
-        if M % NI or (M // NI) % 128 or n_out % groups:
+        if M % NI or (M // NI) % 64 or n_out % groups:
             return None
         if self.ws_bytes and self.lib.pm_gemm_workspace_bytes(M, n_out, K, 0) > 0:
             return None  # a split-K shape: its epilogue runs in the reduce pass, keep the separate statistics
-        return torch.empty((M // 128) * n_out * 2, dtype=torch.float32, device=self.device)
+        return torch.empty((M // 64) * n_out * 2, dtype=torch.float32, device=self.device)
 
     def _stats_end(self, out, col, stats):
         if stats is None:
@@ -89,7 +89,7 @@ class HipOps:
             return out, self.groupnorm_stats(out, NI, groups)
         M, n_out = out.shape
         tot = torch.empty(NI, groups, 2, dtype=torch.float32, device=self.device)
-        rc = self.lib.pm_groupnorm_finalize_colstats(_ptr(col), _ptr(tot), M // 128, n_out, NI, groups, self._stream())
+        rc = self.lib.pm_groupnorm_finalize_colstats(_ptr(col), _ptr(tot), M // 64, n_out, NI, groups, self._stream())
         capi.check(rc, "pm_groupnorm_finalize_colstats")
         return out, tot
 
