@@ -53,13 +53,24 @@ __global__ void gn_stats_kernel(const TI* __restrict__ x, int64_t ldx, float* __
   float s[8], ss[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
-  for (int r = r0 + rlane; r < r1; r += k) {
-    float v[8];
-    load8<TI>(xp + (int64_t)r * ldx, v);
+  // four independent row loads in flight per thread (one per iteration left the pass latency-bound);
+  // accumulated in row order, so the sums are those of the one-row-at-a-time walk
+  for (int r = r0 + rlane; r < r1; r += 4 * k) {
+    float v[4][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      s[e] += v[e];
-      ss[e] = fmaf(v[e], v[e], ss[e]);
+    for (int u = 0; u < 4; ++u) {
+      const int ru = r + u * k;
+      load8<TI>(xp + (int64_t)(ru < r1 ? ru : r) * ldx, v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (r + u * k < r1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s[e] += v[u][e];
+          ss[e] = fmaf(v[u][e], v[u][e], ss[e]);
+        }
+      }
     }
   }
   // per-thread partials -> LDS [rlane][2][C]; then fixed-order reductions (deterministic)
@@ -138,55 +149,139 @@ __global__ __launch_bounds__(256) void gn_finalize_colstats_kernel(const float* 
   }
 }
 
-// grid (nblocks, NI); block 256.  sh: scale[C], shift[C]
+// grid (ceil(P / rows_per_block), NI); block gn_threads(C/8) = (C/8) * k threads: a thread keeps one
+// 8-channel column (its scale/shift live in registers: no LDS, no barrier, no index division) and walks
+// rows r0 + rlane, + k, ... with four independent row loads in flight.
 template <typename TI, typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const TI* __restrict__ x, int64_t ldx,
-                                                       const float* __restrict__ totals,
-                                                       const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta,
-                                                       T* __restrict__ y, int64_t ldy, int P, int C,
-                                                       int groups, float inv_count, float eps,
-                                                       int silu) {
-  extern __shared__ __attribute__((aligned(16))) float sh[];  // [2][C] + [2][groups]
-  float* scale = sh;
-  float* shift = sh + C;
-  float* gstat = sh + 2 * C;  // mean, rstd per group
-  const int inst = blockIdx.y;
-  if ((int)threadIdx.x < groups) {
-    const float a = totals[((int64_t)inst * groups + threadIdx.x) * 2];
-    const float b = totals[((int64_t)inst * groups + threadIdx.x) * 2 + 1];
-    const float mean = a * inv_count;
-    float var = b * inv_count - mean * mean;
-    if (var < 0.f) var = 0.f;
-    gstat[threadIdx.x * 2] = mean;
-    gstat[threadIdx.x * 2 + 1] = rsqrtf(var + eps);
-  }
-  __syncthreads();
-  const int cpg = C / groups;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const int g = c / cpg;
-    const float sc = gstat[g * 2 + 1] * gamma[c];
-    scale[c] = sc;
-    shift[c] = beta[c] - gstat[g * 2] * sc;
-  }
-  __syncthreads();
+__global__ void gn_apply_kernel(const TI* __restrict__ x, int64_t ldx, const float* __restrict__ totals,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                T* __restrict__ y, int64_t ldy, int P, int C, int groups, float inv_count,
+                                float eps, int silu, int rows_per_block) {
   const int CV = C >> 3;
-  const int64_t total = (int64_t)P * CV;
-  const TI* xp = x + (int64_t)inst * P * ldx;
-  T* yp = y + (int64_t)inst * P * ldy;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t r = i / CV;
-    const int cv = (int)(i - r * CV);
-    Pack8<T> o;
-    float t[8];
-    load8<TI>(xp + r * ldx + cv * 8, t);
+  const int k = blockDim.x / CV;
+  const int cv = threadIdx.x % CV, rlane = threadIdx.x / CV;
+  const int inst = blockIdx.y;
+  const int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  if (r1 > P) r1 = P;
+  const TI* xp = x + (int64_t)inst * P * ldx + cv * 8;
+  T* yp = y + (int64_t)inst * P * ldy + cv * 8;
+  float sc[8], sh[8];
+  bool have = false;
+  for (int r = r0 + rlane; r < r1; r += 4 * k) {
+    float t[4][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v = fmaf(t[e], scale[cv * 8 + e], shift[cv * 8 + e]);
-      if (silu) v = silu_f(v);
-      o.e[e] = from_f32<T>(v);
+    for (int u = 0; u < 4; ++u) {
+      const int ru = r + u * k;
+      load8<TI>(xp + (int64_t)(ru < r1 ? ru : r) * ldx, t[u]);
     }
-    st_global16(yp + r * ldy + cv * 8, o.u);
+    if (!have) {  // (behind the first row loads in program order: its loads overlap theirs)
+      have = true;
+      const int cpg = C / groups;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + cv * 8);
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + cv * 8 + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + cv * 8);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + cv * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int g = (cv * 8 + e) / cpg;
+        const float a = totals[((int64_t)inst * groups + g) * 2];
+        const float b = totals[((int64_t)inst * groups + g) * 2 + 1];
+        const float mean = a * inv_count;
+        float var = b * inv_count - mean * mean;
+        if (var < 0.f) var = 0.f;
+        const float rstd = rsqrtf(var + eps);
+        sc[e] = rstd * (e < 4 ? g0[e & 3] : g1[e & 3]);
+        sh[e] = (e < 4 ? b0[e & 3] : b1[e & 3]) - mean * sc[e];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ru = r + u * k;
+      if (ru < r1) {
+        Pack8<T> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = fmaf(t[u][e], sc[e], sh[e]);
+          if (silu) v = silu_f(v);
+          o.e[e] = from_f32<T>(v);
+        }
+        st_global16(yp + (int64_t)ru * ldy, o.u);
+      }
+    }
+  }
+}
+
+// LayerNorm: LPR lanes per row (16 / 32 / 64), 64/LPR rows per wave, 4 waves per block.  A lane holds up to
+// 8 vectors of 4 channels (C <= 32 * LPR), all loaded before the first reduction: with one row per wave
+// (the fallback below) a C = 320 row keeps 40 lanes busy with two loads each and the pass is latency-bound.
+template <typename TI> __device__ __forceinline__ void load4(const TI* p, float (&v)[4]) {
+  if constexpr (std::is_same<TI, float>::value) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = a[e];
+  } else {
+    Pack4<TI> t;
+    t.u = *reinterpret_cast<const u32x2*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = to_f32(t.e[e]);
+  }
+}
+
+template <typename TI, typename T, int LPR>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const TI* __restrict__ x, int64_t ldx,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             T* __restrict__ y, int64_t ldy, int M, int C,
+                                                             float eps) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane % LPR;
+  const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+  const bool live = row < M;
+  const int C4 = C >> 2;
+  const TI* xp = x + (int64_t)(live ? row : 0) * ldx;
+  float v[8][4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c4 = sub + LPR * i;
+    if (c4 < C4) {
+      load4<TI>(xp + c4 * 4, v[i]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += v[i][e];
+    }
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (sub + LPR * i < C4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i][e] - mean;
+        ss = fmaf(d, d, ss);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float rstd = rsqrtf(ss / (float)C + eps);
+  if (!live) return;
+  T* yp = y + (int64_t)row * ldy;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c4 = sub + LPR * i;
+    if (c4 < C4) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c4 * 4);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c4 * 4);
+      Pack4<T> o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o.e[e] = from_f32<T>(fmaf((v[i][e] - mean) * rstd, g[e], b[e]));
+      *reinterpret_cast<u32x2*>(yp + c4 * 4) = o.u;
+    }
   }
 }
 
@@ -325,18 +420,16 @@ extern "C" int pm_groupnorm_apply(const void* x, int64_t ldx, const float* total
   int rc = gn_check(NI, P, C, groups, ldx, in_dtype);
   if (rc) return rc;
   if ((ldy & 7) || ldy < C || count <= 0) return PM_E_SHAPE;
-  const int64_t vecs = P * (C >> 3);
-  int64_t nb = (vecs + 256 * 4 - 1) / (256 * 4);  // ~4 vectors per thread
-  const int64_t cap = (2048 + NI - 1) / NI;
-  if (nb > cap) nb = cap;
-  if (nb < 1) nb = 1;
-  dim3 grid((unsigned)nb, (unsigned)NI);
-  const size_t shmem = (2 * C + 2 * groups) * sizeof(float);
+  const int threads = gn_threads((int)(C >> 3));
+  const int k = threads / (int)(C >> 3);
+  int64_t rpb = 4 * k;  // one batch of four rows per thread; more only to keep the grid under ~8192 blocks
+  while (((P + rpb - 1) / rpb) * NI > 8192) rpb *= 2;
+  dim3 grid((unsigned)((P + rpb - 1) / rpb), (unsigned)NI);
   PM_DISPATCH_IN_OUT(in_dtype, out_dtype, TI, TO,
-                     hipLaunchKernelGGL((gn_apply_kernel<TI, TO>), grid, dim3(256), shmem,
+                     hipLaunchKernelGGL((gn_apply_kernel<TI, TO>), grid, dim3(threads), 0,
                                         (hipStream_t)stream, (const TI*)x, ldx, totals,
                                         gamma, beta, (TO*)y, ldy, (int)P, (int)C, groups,
-                                        (float)(1.0 / count), eps, silu);
+                                        (float)(1.0 / count), eps, silu, (int)rpb);
                      return check_launch());
 }
 
@@ -347,6 +440,21 @@ extern "C" int pm_layernorm(const void* x, int64_t ldx, const float* gamma, cons
   const int64_t amask = (in_dtype == PM_F32) ? 3 : 7;
   if (M < 1 || C < 8 || (C & 7) || C > 4096 || (ldx & amask) || (ldy & 7) || ldx < C || ldy < C)
     return PM_E_SHAPE;
+  if (C <= 2048) {  // several rows per wave
+    const int lpr = C <= 512 ? 16 : (C <= 1024 ? 32 : 64);
+    const int rpb = 4 * (64 / lpr);
+    dim3 g2((unsigned)((M + rpb - 1) / rpb));
+#define PM_LN_ROWS(LPR)                                                                                   \
+  PM_DISPATCH_IN_OUT(in_dtype, out_dtype, TI, TO,                                                         \
+                     hipLaunchKernelGGL((layernorm_rows_kernel<TI, TO, LPR>), g2, dim3(256), 0,           \
+                                        (hipStream_t)stream, (const TI*)x, ldx, gamma, beta, (TO*)y, ldy, \
+                                        (int)M, (int)C, eps);                                             \
+                     return check_launch())
+    if (lpr == 16) PM_LN_ROWS(16);
+    if (lpr == 32) PM_LN_ROWS(32);
+    PM_LN_ROWS(64);
+#undef PM_LN_ROWS
+  }
   dim3 grid((unsigned)((M + 3) / 4));
   PM_DISPATCH_IN_OUT(in_dtype, out_dtype, TI, TO,
                      hipLaunchKernelGGL((layernorm_kernel<TI, TO>), grid, dim3(256), 0,

@@ -158,18 +158,26 @@ class DDIMSampler:
         uc = unconditional_conditioning if use_cfg else None
         unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
         graphable = (self.use_graph and getattr(ops, "supports_graphs", False) and isinstance(c, dict)
-                     and getattr(unet, "fp", None) is None and self.cfg_parallel is None and x.is_cuda)
-        if graphable:
-            tensors = [v for d in (c, uc or {}) for lst in d.values() for v in lst] + ([fs] if torch.is_tensor(fs) else [])
+                     and getattr(unet, "fp", None) is None and x.is_cuda)
+        pair = self.cfg_parallel is not None and use_cfg  # this rank runs ONE branch, then one exchange
+
+        def replay(cc, uu):
+            tensors = [v for d in (cc, uu or {}) for lst in d.values() for v in lst] + ([fs] if torch.is_tensor(fs) else [])
             key = (tuple(x.shape), tuple((v.data_ptr(), tuple(v.shape)) for v in tensors), tuple(sorted(kwargs)))
             g = self._graphs.get(key)
             if g is None:
                 self._graphs.clear()  # one live graph: its private pool holds a forward's activations
-                g = self._graphs[key] = _ForwardGraph(self.model, x, t, c, uc, fs, kwargs)
-            e_c, e_u = g(x, t)
-        elif self.cfg_parallel is not None and use_cfg:
+                g = self._graphs[key] = _ForwardGraph(self.model, x, t, cc, uu, fs, kwargs)
+            return g(x, t)
+
+        if pair:
+            # the branch forward has no collective inside (frames unsharded): it replays as a graph too,
+            # the exchange of the two branch outputs stays outside the graph
             mine = c if self.cfg_parallel.branch == 0 else uc
-            e_c, e_u = self.cfg_parallel.exchange(self.model.apply_model(x, t, mine, fs=fs, **kwargs))
+            e_mine = replay(mine, None)[0] if graphable else self.model.apply_model(x, t, mine, fs=fs, **kwargs)
+            e_c, e_u = self.cfg_parallel.exchange(e_mine)
+        elif graphable and self.cfg_parallel is None:
+            e_c, e_u = replay(c, uc)
         else:
             e_c = self.model.apply_model(x, t, c, fs=fs, **kwargs)
             e_u = self.model.apply_model(x, t, uc, fs=fs, **kwargs) if use_cfg else None
