@@ -128,7 +128,7 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restri
 __global__ __launch_bounds__(256) void gn_finalize_colstats_kernel(const float* __restrict__ colstats,
                                                                    float* __restrict__ totals, int tpi,
                                                                    int C, int groups) {
-  __shared__ float red[512];
+  __shared__ float red[8];
   const int g = blockIdx.x, inst = blockIdx.y;
   const int cpg = C / groups;
   const int n = tpi * cpg;
@@ -139,13 +139,17 @@ __global__ __launch_bounds__(256) void gn_finalize_colstats_kernel(const float* 
     a += src[0];
     b += src[1];
   }
-  red[threadIdx.x] = a;
-  red[256 + threadIdx.x] = b;
+  // fixed reduction tree (deterministic): xor-shuffle inside each wave, then the 4 wave sums in order
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6] = a;
+    red[4 + (threadIdx.x >> 6)] = b;
+  }
   __syncthreads();
   if (threadIdx.x < 2) {
-    float t = 0.f;
-    for (int j = 0; j < 256; ++j) t += red[threadIdx.x * 256 + j];
-    totals[((int64_t)inst * groups + g) * 2 + threadIdx.x] = t;
+    const float* r = red + 4 * threadIdx.x;
+    totals[((int64_t)inst * groups + g) * 2 + threadIdx.x] = ((r[0] + r[1]) + r[2]) + r[3];
   }
 }
 

@@ -38,7 +38,12 @@ def image_guided_synthesis(diffusion_model, diffusion_conditioning, img_emb, uc_
     """model.py:703-781 with the encoders factored out.  Returns (batch, n_samples, c, t, h, w):
     decoded frames if `decode_first_stage` is given, else latents."""
     if multiple_cond_cfg:
-        raise NotImplementedError("DDIMSampler_multicond (SURVEY §8f row 4) is not built yet")
+        # SURVEY §8f row 4.  The reference's DDIMSampler_multicond cannot run on this model either: its
+        # make_schedule (ddim_multiplecond.py:40) calls np.sqrt on the bf16 alphas_cumprod buffer that
+        # DDPM.register_schedule leaves behind (ddpm3d.py:159) and raises "Got unsupported ScalarType
+        # BFloat16" (pinned by tests/test_oracle_vs_reference.py), so there is no behaviour to match.
+        raise NotImplementedError("multiple_cond_cfg: the reference's DDIMSampler_multicond raises TypeError on the "
+                                  "bf16 schedule buffers (ddim_multiplecond.py:40); no three-way CFG path exists")
     sampler = sampler or DDIMSampler(diffusion_model)
     batch_size = noise_shape[0]
     dev = z_cond.device

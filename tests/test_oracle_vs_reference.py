@@ -36,3 +36,23 @@ def test_fixture_regeneration_is_reproducible(tmp_path, monkeypatch):
     assert sorted(new.files) == sorted(old.files)
     for k in new.files:
         assert np.array_equal(new[k], old[k], equal_nan=True), k
+
+
+def test_multicond_sampler_is_dead_in_the_reference():
+    """`multiple_cond_cfg=True` selects ddim_multiplecond.DDIMSampler (model.py:705), whose
+    make_schedule runs np.sqrt on the bf16 `alphas_cumprod` buffer and raises; our wm layer therefore
+    refuses the flag instead of inventing a behaviour."""
+    rh._install_shims()
+    import lvdm.models.samplers.ddim_multiplecond as refmc
+    from open_pandora_amd import wm
+
+    class CPUSampler(refmc.DDIMSampler):
+        def register_buffer(self, name, attr):
+            setattr(self, name, attr)
+
+    m = rh.reference_diffusion(dict(model_channels=64))
+    assert m.alphas_cumprod.dtype == torch.bfloat16
+    with pytest.raises(TypeError, match="BFloat16"):
+        CPUSampler(m).make_schedule(5, "uniform_trailing", 0.0, verbose=False)
+    with pytest.raises(NotImplementedError, match="multiple_cond_cfg"):
+        wm.image_guided_synthesis(None, None, None, None, None, None, (1, 4, 16, 8, 8), multiple_cond_cfg=True)
