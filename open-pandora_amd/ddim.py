@@ -134,7 +134,7 @@ class DDIMSampler:
             if cbs != batch_size:
                 print(f"Warning: Got {cbs} conditionings but batch-size is {batch_size}")
         for flag, name in ((quantize_x0, "quantize_x0"), (score_corrector is not None, "score_corrector"),
-                           (noise_dropout > 0.0, "noise_dropout"), (guidance_rescale > 0.0, "guidance_rescale")):
+                           (noise_dropout > 0.0, "noise_dropout")):
             if flag:
                 raise NotImplementedError(f"{name} is not on the Open-Pandora generate() path")
         self.make_schedule(ddim_num_steps=S, ddim_discretize=timestep_spacing, ddim_eta=eta, verbose=schedule_verbose)
@@ -143,11 +143,12 @@ class DDIMSampler:
                                   x0=x0, temperature=temperature, x_T=x_T, log_every_t=log_every_t,
                                   unconditional_guidance_scale=unconditional_guidance_scale,
                                   unconditional_conditioning=unconditional_conditioning, verbose=verbose,
-                                  precision=precision, fs=fs, **kwargs)
+                                  precision=precision, fs=fs, guidance_rescale=guidance_rescale, **kwargs)
 
     @torch.no_grad()
     def p_sample_ddim(self, x, c, t, index, temperature=1.0, unconditional_guidance_scale=1.0,
-                      unconditional_conditioning=None, fs=None, noise=None, want_x0=True, step=None, **kwargs):
+                      unconditional_conditioning=None, fs=None, noise=None, want_x0=True, step=None,
+                      guidance_rescale=0.0, **kwargs):
         """One denoising step (ddim.py:218-290): two U-Net forwards when CFG is on, then the fused
         update kernel.  `t` is the (b,) long tensor of the current DDPM timestep, `index` its position
         in the DDIM schedule.  `noise` (f32, x-shaped) overrides the device RNG draw."""
@@ -181,6 +182,17 @@ class DDIMSampler:
         else:
             e_c = self.model.apply_model(x, t, c, fs=fs, **kwargs)
             e_u = self.model.apply_model(x, t, uc, fs=fs, **kwargs) if use_cfg else None
+        cfg_scale = float(unconditional_guidance_scale)
+        if use_cfg and guidance_rescale > 0.0:
+            # rescale_noise_cfg (utils_diffusion.py:147-158, ddim.py:240-241): match the guided output's
+            # per-sample std to the conditional one, blended by guidance_rescale.  A reduction over the
+            # whole (655k-element) model output: plain torch on the f32 outputs, then the fused update
+            # kernel takes the finished model output (e_u = None, cfg = 1)
+            dims = list(range(1, e_c.dim()))
+            v = e_u + cfg_scale * (e_c - e_u)
+            v = guidance_rescale * (v * (e_c.std(dim=dims, keepdim=True) / v.std(dim=dims, keepdim=True))) \
+                + (1.0 - guidance_rescale) * v
+            e_c, e_u, cfg_scale = v, None, 1.0
         sc = self.step_scalars(index, step)
         if sc["sigma"] != 0.0:
             if noise is None:
@@ -190,13 +202,13 @@ class DDIMSampler:
         else:
             noise = None
         return ops.ddim_update(x, e_c.contiguous(), None if e_u is None else e_u.contiguous(), noise,
-                               float(unconditional_guidance_scale), want_x0=want_x0, **sc)
+                               cfg_scale, want_x0=want_x0, **sc)
 
     @torch.no_grad()
     def ddim_sampling(self, cond, shape, x_T=None, callback=None, mask=None, x0=None, img_callback=None,
                       log_every_t=100, temperature=1.0, unconditional_guidance_scale=1.0,
                       unconditional_conditioning=None, verbose=True, precision=None, fs=None,
-                      noise_fn=None, **kwargs):
+                      noise_fn=None, guidance_rescale=0.0, **kwargs):
         ops = self._ops()
         device = ops.device
         img = torch.randn(shape, device=device) if x_T is None else x_T.to(device)
@@ -229,7 +241,7 @@ class DDIMSampler:
                                               unconditional_guidance_scale=unconditional_guidance_scale,
                                               unconditional_conditioning=unconditional_conditioning, fs=fs,
                                               noise=noise_fn(i, shape) if noise_fn is not None else None, step=step,
-                                              **model_kwargs)
+                                              guidance_rescale=guidance_rescale, **model_kwargs)
             if callback:
                 callback(i)
             if img_callback:

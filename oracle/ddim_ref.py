@@ -53,7 +53,7 @@ def ddim_tables(tables, S, eta, spacing):
 
 @torch.no_grad()
 def ddim_sample(apply_model, tables, x_T, cond, uncond, S, eta, cfg_scale, spacing="uniform_trailing",
-                noises=None, fs=None, keep_pred_x0=False):
+                noises=None, fs=None, keep_pred_x0=False, guidance_rescale=0.0):
     """apply_model(x, t, cond, fs) -> v prediction.  noises: list of S tensors (one per loop
     iteration, same shape as x_T) consumed when eta > 0.  Returns (x_0 sample, [pred_x0 per step])."""
     d = ddim_tables(tables, S, eta, spacing)
@@ -71,6 +71,10 @@ def ddim_sample(apply_model, tables, x_T, cond, uncond, S, eta, cfg_scale, spaci
         else:
             e_u = apply_model(x, t, uncond, fs)
             v = e_u + cfg_scale * (e_c - e_u)
+            if guidance_rescale > 0.0:  # rescale_noise_cfg, utils_diffusion.py:147-158 (ddim.py:240-241)
+                dims = list(range(1, v.dim()))
+                resc = v * (e_c.std(dim=dims, keepdim=True) / v.std(dim=dims, keepdim=True))
+                v = guidance_rescale * resc + (1 - guidance_rescale) * v
         sa = tables["sqrt_alphas_cumprod"][t].reshape(size)         # bf16 scalars, promoted by x
         sm = tables["sqrt_one_minus_alphas_cumprod"][t].reshape(size)
         e_t = sa * v + sm * x

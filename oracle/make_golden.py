@@ -135,6 +135,26 @@ def gen_ddim_small():
     save("ddim_small.npz", **out)
 
 
+def gen_ddim_rescale():
+    """guidance_rescale > 0 (rescale_noise_cfg, utils_diffusion.py:147-158) through the real sampler."""
+    rh._install_shims()
+    import lvdm.models.samplers.ddim as refddim
+    out = {}
+    m = rh.reference_diffusion(dict(model_channels=64))
+    m.model.diffusion_model.load_state_dict(synth.synth_state_dict(m.model.diffusion_model, seed=WEIGHT_SEED))
+    ins, cond, uc = _small_setup()
+    for S, eta, cfg, gres in gr.DDIM_RESCALE_CASES:
+        noises = iter(gr.noises(ins["x_T"].shape, S))
+        refddim.noise_like = lambda shape, device, repeat=False: next(noises)
+        smp = rh.reference_sampler(m)
+        y, _ = smp.sample(S=S, batch_size=1, shape=(4, 16, 8, 8), conditioning=cond, verbose=False,
+                          unconditional_guidance_scale=cfg, unconditional_conditioning=uc, eta=eta,
+                          fs=torch.tensor([15]), timestep_spacing="uniform_trailing", x_T=ins["x_T"],
+                          guidance_rescale=gres)
+        out[f"S{S}_eta{eta:g}_cfg{cfg:g}_gr{gres:g}"] = y.numpy()
+    save("ddim_small_rescale.npz", **out)
+
+
 def gen_full(traj):
     torch.set_num_threads(os.cpu_count() or 8)
     t0 = time.time()
@@ -223,7 +243,12 @@ if __name__ == "__main__":
     ap.add_argument("--traj", action="store_true")
     ap.add_argument("--oracle-72x128", action="store_true")
     ap.add_argument("--ae", action="store_true")
+    ap.add_argument("--rescale", action="store_true")
     a = ap.parse_args()
+    if a.rescale:
+        assert rh.available()
+        gen_ddim_rescale()
+        sys.exit(0)
     if a.ae:
         assert rh.available()
         gen_ae()
@@ -239,3 +264,4 @@ if __name__ == "__main__":
         gen_modules()
         gen_unet_small()
         gen_ddim_small()
+        gen_ddim_rescale()

@@ -83,3 +83,16 @@ def test_graph_ddim_small(S, eta, cfg):
     else:
         assert rel(y, g) < 5e-5
     assert len(inter["x_inter"]) >= 2
+
+
+@pytest.mark.parametrize("S,eta,cfg,gres", gr.DDIM_RESCALE_CASES)
+def test_graph_ddim_guidance_rescale(S, eta, cfg, gres):
+    g = load("ddim_small_rescale.npz")[f"S{S}_eta{eta:g}_cfg{cfg:g}_gr{gres:g}"]
+    pm = LatentVisualDiffusion(small_unet(64))
+    ins, cond, uc = gr.sampler_inputs(8, 8)
+    ns = gr.noises(ins["x_T"].shape, S)
+    y, _ = DDIMSampler(pm).sample(S=S, batch_size=1, shape=(4, 16, 8, 8), conditioning=cond, verbose=False,
+                                  unconditional_guidance_scale=cfg, unconditional_conditioning=uc, eta=eta,
+                                  fs=torch.tensor([15]), timestep_spacing="uniform_trailing", x_T=ins["x_T"],
+                                  noise_fn=lambda i, shape: ns[i], guidance_rescale=gres)
+    assert rel(y, g) < 5e-5

@@ -112,3 +112,17 @@ def test_ddim_small_against_reference(S, eta, cfg):
         assert torch.isnan(y).any()
     else:
         assert rel(y, g) < 5e-5
+
+
+@pytest.mark.parametrize("S,eta,cfg,gres", gr.DDIM_RESCALE_CASES)
+def test_ddim_guidance_rescale_against_reference(S, eta, cfg, gres):
+    """rescale_noise_cfg (utils_diffusion.py:147-158) on the sampler path (ddim.py:240-241)."""
+    g = load("ddim_small_rescale.npz")[f"S{S}_eta{eta:g}_cfg{cfg:g}_gr{gres:g}"]
+    kw = dict(RH_KW, model_channels=64)
+    sd = _sd(U.UNetModel(**kw))
+    ins, cond, uc = gr.sampler_inputs(8, 8)
+    apply = lambda x, t, c, fs: unet_ref.unet_forward(sd, torch.cat([x] + c["c_concat"], 1), t,
+                                                      torch.cat(c["c_crossattn"], 1), fs, model_channels=64)
+    y, _ = ddim_ref.ddim_sample(apply, ddim_ref.schedule_tables(), ins["x_T"], cond, uc, S, eta, cfg,
+                                noises=gr.noises(ins["x_T"].shape, S), fs=torch.tensor([15]), guidance_rescale=gres)
+    assert np.isfinite(g).all() and rel(y, g) < 5e-5

@@ -62,6 +62,23 @@ def test_ddim_small_trajectory(hip_ops_factory, dtype, S, eta, cfg):
     assert err <= TRAJ_TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("S,eta,cfg,gres", gr.DDIM_RESCALE_CASES)
+def test_ddim_guidance_rescale_trajectory(hip_ops_factory, dtype, S, eta, cfg, gres):
+    g = load("ddim_small_rescale.npz")[f"S{S}_eta{eta:g}_cfg{cfg:g}_gr{gres:g}"]
+    pm = LatentVisualDiffusion(small_model(64, hip_ops_factory(dtype)))
+    ins, cond, uc = gr.sampler_inputs(8, 8)
+    dev = lambda c: {k: [t.cuda() for t in v] for k, v in c.items()}
+    ns = gr.noises(ins["x_T"].shape, S)
+    y, _ = DDIMSampler(pm).sample(S=S, batch_size=1, shape=(4, 16, 8, 8), conditioning=dev(cond), verbose=False,
+                                  unconditional_guidance_scale=cfg, unconditional_conditioning=dev(uc), eta=eta,
+                                  fs=torch.tensor([15]).cuda(), timestep_spacing="uniform_trailing",
+                                  x_T=ins["x_T"].cuda(), noise_fn=lambda i, shape: ns[i], guidance_rescale=gres)
+    err = rel(y.cpu(), g)
+    print(f"\n[parity] ddim guidance_rescale S={S} eta={eta} cfg={cfg} gr={gres} {dtype}: rel err {err:.2e}")
+    assert err <= TRAJ_TOL[dtype]
+
+
 def _digest_err(t, g, prefix):
     sl = gr.digest_of(t.cpu(), g[f"{prefix}/stride"], len(g[f"{prefix}/slice"]))
     return rel(sl, g[f"{prefix}/slice"]), float(t.float().std()), float(g[f"{prefix}/std"])
