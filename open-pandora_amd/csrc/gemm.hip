@@ -8,8 +8,8 @@
 // DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write; the im2col gather and the padding
 // are per-lane SOURCE addresses); an f32 A operand (residual stream) is staged through registers and
 // rounded on the way.  LDS rows are 128 B with the 16-byte chunk index XOR-ed by (row & 7) - applied
-// on the source side - so the ds_read_b128 fragment reads spread over the banks.  The epilogue goes through LDS
-// (f32) so that residual loads and output stores are full 16-byte row segments.
+// on the source side - so the ds_read_b128 fragment reads spread over the banks.  The epilogue works from
+// registers (operands swapped in the MFMA, W rows interleaved by the loader: epilogue_regs), 16 bytes per lane.
 #include <stdlib.h>
 #include <type_traits>
 #include "common.hpp"
@@ -60,6 +60,177 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + (bid >> 3);
+}
+
+// Register-direct epilogue shared by both GEMM kernels.  The MFMAs run with the operands swapped (W
+// fragment as the MFMA "A" operand), so a wave's accumulator tile is C^T: lane (fr, fq) holds output row
+// m = i*16 + fr and, for column block j, the 4 CONSECUTIVE columns 4*fq .. 4*fq+3.  With the loaders'
+// column interleave (cperm below) a block pair (2jp, 2jp+1) gives 8 ADJACENT output columns per lane, so
+// bias / activation / residual / statistics / store all happen in registers with 16-byte accesses: no LDS
+// round trip, no barrier (in-kernel stamps: the LDS-staged epilogue cost ~8600 cycles per 128x128 tile,
+// as much as 12 K-steps of the main loop).
+//   LDS row pr of the W tile holds output column n0 + cperm(pr); GEGLU keeps the natural order (its
+//   [16 value | 16 gate] weight packing IS the block pair).
+__device__ __forceinline__ int cperm(int pr, bool geglu) {
+  const int nn = pr & 15, jb = (pr >> 4) & 3;
+  return geglu ? pr : (pr & ~63) + (jb >> 1) * 32 + (nn >> 2) * 8 + (jb & 1) * 4 + (nn & 3);
+}
+// bias of this lane's 16 output columns, bv[j][r] <-> column block j, column 4*fq + r in MFMA order
+__device__ __forceinline__ void load_bias_regs(const GemmParams& p, float (&bv)[4][4], int n0, int wn, int fq) {
+  const float* bias_p = (p.splits > 1) ? nullptr : p.bias;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = (p.act == PM_ACT_GEGLU) ? n0 + wn * 64 + j * 16 + 4 * fq + r
+                                            : n0 + wn * 64 + (j >> 1) * 32 + fq * 8 + (j & 1) * 4 + r;
+      bv[j][r] = (bias_p != nullptr && n < p.N) ? bias_p[n] : 0.f;
+    }
+}
+// rows m0 + wm*64 + i*16 + fr, columns n0 + wn*64 + ...; sblock = index of this wave's 64-row block in colstats
+template <typename T>
+__device__ __forceinline__ void epilogue_regs(const GemmParams& p, f32x4 (&acc)[4][4], const float (&bv)[4][4],
+                                              int m0, int n0, int wm, int wn, int fr, int fq, int sblock,
+                                              int split) {
+  const bool partial = p.splits > 1;
+  // The MFMAs ran with the operands swapped (W fragment as "A"), so the accumulator tile is C^T: lane
+  // (fr, fq) holds row m = i*16 + fr and, for column block j, the 4 CONSECUTIVE columns 4*fq .. 4*fq+3.
+  // With the loader's column interleave a block pair (2jp, 2jp+1) gives 8 adjacent columns per lane:
+  // bias / activation / residual / statistics / store all happen in registers with 16-byte accesses -
+  // no LDS round trip, no barrier (the LDS-staged epilogue cost ~8600 cycles per tile = 12 K-steps).
+  const int act = partial ? PM_ACT_NONE : p.act;
+  const bool geglu = (act == PM_ACT_GEGLU);
+  const int nout = geglu ? (p.N >> 1) : p.N;
+  T* __restrict__ Cg = reinterpret_cast<T*>(p.C);
+  const T* __restrict__ Rg = (partial || p.res32) ? nullptr : reinterpret_cast<const T*>(p.R);
+  float* __restrict__ Cf = partial ? p.ws + (int64_t)split * p.M * p.N : reinterpret_cast<float*>(p.C);
+  const float* __restrict__ Rf = (partial || !p.res32) ? nullptr : reinterpret_cast<const float*>(p.R);
+  const bool out32 = partial || p.out32 != 0;
+  const int64_t ldc = partial ? p.N : p.ldc;
+  const bool want_stats = (p.colstats != nullptr) && !partial;
+  if (geglu) {
+    // value block 2jj, gate block 2jj+1 (weights packed [16 value | 16 gate]): 4 output columns per lane
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + fr;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int n = (n0 >> 1) + wn * 32 + jj * 16 + 4 * fq;
+        if (m < p.M && n < nout) {
+          Pack4<T> ov;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            ov.e[r] = from_f32<T>((acc[i][2 * jj][r] + bv[2 * jj][r]) * gelu_erf_f(acc[i][2 * jj + 1][r] + bv[2 * jj + 1][r]));
+          T* cptr = Cg + (int64_t)m * ldc + n;
+          if (n + 4 <= nout && ((ldc & 3) == 0))
+            *reinterpret_cast<u32x2*>(cptr) = ov.u;
+          else
+            for (int e = 0; e < 4 && n + e < nout; ++e) cptr[e] = ov.e[e];
+        }
+      }
+    }
+  } else {
+    float cs[2][8], cq[2][8];
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cs[jp][e] = cq[jp][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + fr;
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        const int n = n0 + wn * 64 + jp * 32 + fq * 8;
+        if (m < p.M && n < nout) {
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[i][2 * jp][r] + bv[2 * jp][r];
+            v[4 + r] = acc[i][2 * jp + 1][r] + bv[2 * jp + 1][r];
+          }
+          if (act == PM_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+          }
+          const bool fullr = (n + 8 <= nout);
+          if (Rf != nullptr) {
+            const float* rptr = Rf + (int64_t)m * p.ldr + n;
+            if (fullr && ((p.ldr & 3) == 0)) {
+              const f32x4 r0 = *reinterpret_cast<const f32x4*>(rptr);
+              const f32x4 r1 = *reinterpret_cast<const f32x4*>(rptr + 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v[e] += r0[e];
+                v[e + 4] += r1[e];
+              }
+            } else {
+              for (int e = 0; e < 8 && n + e < nout; ++e) v[e] += rptr[e];
+            }
+          } else if (Rg != nullptr) {
+            const T* rptr = Rg + (int64_t)m * p.ldr + n;
+            if (fullr && ((p.ldr & 7) == 0)) {
+              Pack8<T> rv;
+              rv.u = ld_global16(rptr);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += to_f32(rv.e[e]);
+            } else {
+              for (int e = 0; e < 8 && n + e < nout; ++e) v[e] += to_f32(rptr[e]);
+            }
+          }
+          if (want_stats) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (n + e < nout) {
+                cs[jp][e] += v[e];
+                cq[jp][e] = fmaf(v[e], v[e], cq[jp][e]);
+              }
+          }
+          if (out32) {
+            float* cptr = Cf + (int64_t)m * ldc + n;
+            if (fullr && ((ldc & 3) == 0)) {
+              *reinterpret_cast<f32x4*>(cptr) = f32x4{v[0], v[1], v[2], v[3]};
+              *reinterpret_cast<f32x4*>(cptr + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            } else {
+              for (int e = 0; e < 8 && n + e < nout; ++e) cptr[e] = v[e];
+            }
+          } else {
+            T* cptr = Cg + (int64_t)m * ldc + n;
+            if (fullr && ((ldc & 7) == 0)) {
+              Pack8<T> ov;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) ov.e[e] = from_f32<T>(v[e]);
+              st_global16(cptr, ov.u);
+            } else {
+              for (int e = 0; e < 8 && n + e < nout; ++e) cptr[e] = from_f32<T>(v[e]);
+            }
+          }
+        }
+      }
+    }
+    if (want_stats) {  // column sums of this wave's 64 rows: in-lane over i, then a fixed xor tree over fr
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) {
+            cs[jp][e] += __shfl_xor(cs[jp][e], o, 64);
+            cq[jp][e] += __shfl_xor(cq[jp][e], o, 64);
+          }
+        }
+      if (fr == 0 && sblock * 64 < p.M) {  // (a ragged last tile has no second block)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          const int n = n0 + wn * 64 + jp * 32 + fq * 8;
+          float* dst = p.colstats + ((int64_t)sblock * nout + n) * 2;
+          for (int e = 0; e < 8 && n + e < nout; ++e) {
+            dst[2 * e] = cs[jp][e];
+            dst[2 * e + 1] = cq[jp][e];
+          }
+        }
+      }
+    }
+  }
 }
 
 // BIG = false: 128x128 tile, 4 waves, 2 LDS stages, 2 workgroups per CU (any shape, split-K, f32 A).
@@ -124,7 +295,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const GemmPara
   int a_y[4], a_x[4];
 #pragma unroll
   for (int j = 0; j < BP; ++j) {
-    int n = n0 + lr + RSTEP * j;
+    int n = n0 + cperm(lr + RSTEP * j, p.act == PM_ACT_GEGLU);  // LDS row -> output column (epilogue_regs)
     if (n > p.N - 1) n = p.N - 1;
     b_off[j] = (uint32_t)(((int64_t)n * p.ldw + lc * 8) * 2);
   }
@@ -268,6 +439,8 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const GemmPara
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bv[4][4];  // bias of this lane's columns: requested now, needed in the epilogue
+  load_bias_regs(p, bv, n0, wn, fq);
 
   // fragment read offsets: row & 7 == fr & 7 for every MFMA block of this wave, so the swizzled slot
   // depends on the k-step only; the block index becomes an immediate offset of the ds_read_b128
@@ -317,7 +490,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const GemmPara
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(a[ks][i].v, b[ks][j].v, acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(b[ks][j].v, a[ks][i].v, acc[i][j]);  // C^T: see epilogue_regs
     }
     if constexpr (BIG) {
       buf = (buf == 2) ? 0 : buf + 1;
@@ -327,161 +500,9 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const GemmPara
       buf ^= 1;
     }
   }
-  if constexpr (BIG) __syncthreads();  // all fragment reads done before the stages become the epilogue scratch
-
-  // ---------------- epilogue ----------------
+  // ---------------- epilogue: registers -> global (no LDS staging, no barrier) ----------------
   // split-K slices store raw f32 partials into their slab; bias/act/residual run in the reduce pass
-  const bool partial = p.splits > 1;
-  const float* bias_p = partial ? nullptr : p.bias;
-  const int act = partial ? PM_ACT_NONE : p.act;
-  // acc[i][j][r] <-> m = wm*64 + i*16 + 4*fq + r,  n = wn*64 + j*16 + fr
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = n0 + wn * 64 + j * 16 + fr;
-    const float bv = (bias_p != nullptr && n < p.N) ? bias_p[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] += bv;
-  }
-  const bool geglu = (act == PM_ACT_GEGLU);
-  if (act == PM_ACT_SILU) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = silu_f(acc[i][j][r]);
-  } else if (geglu) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          acc[i][jj][r] = acc[i][2 * jj][r] * gelu_erf_f(acc[i][2 * jj + 1][r]);
-  }
-  const int tw = geglu ? 64 : 128;          // tile width in output columns
-  const int wcols = tw >> 1;                // columns per wave
-  const int nblk = geglu ? 2 : 4;           // 16-column blocks per wave
-  const int nout = geglu ? (p.N >> 1) : p.N;
-  const int nbase = geglu ? (n0 >> 1) : n0;
-  float* stage = reinterpret_cast<float*>(smem);  // [64][STAGE_LD]
-  T* __restrict__ Cg = reinterpret_cast<T*>(p.C);
-  const T* __restrict__ Rg = (partial || p.res32) ? nullptr : reinterpret_cast<const T*>(p.R);
-  float* __restrict__ Cf = partial ? p.ws + (int64_t)split * p.M * p.N
-                                   : reinterpret_cast<float*>(p.C);  // PM_FLAG_OUT_F32: residual stream
-  const float* __restrict__ Rf = (partial || !p.res32) ? nullptr : reinterpret_cast<const float*>(p.R);
-  const bool out32 = partial || p.out32 != 0;
-  const int64_t ldc = partial ? p.N : p.ldc;
-  const int cpr = tw >> 3;         // 8-column chunks per row
-  const int rpp = NT / cpr;        // rows per pass
-  const int scol = tid % cpr, srow = tid / cpr;
-  // fused GroupNorm statistics of the NEXT layer: column sums of exactly the values stored (f32)
-  const bool want_stats = (p.colstats != nullptr) && !partial;
-  float cs[8], cq[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.f;
-
-  for (int half = 0; half < WMW; ++half) {
-    if (wm == half) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (j < nblk)  // j is a compile-time constant after unrolling (no scratch indexing)
-              stage[(i * 16 + 4 * fq + r) * STAGE_LD + wn * wcols + j * 16 + fr] = acc[i][j][r];
-    }
-    __syncthreads();
-    for (int row = srow; row < 64; row += rpp) {
-      const int m = m0 + half * 64 + row;
-      const int n = nbase + scol * 8;
-      if (m < p.M && n < nout) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(stage + row * STAGE_LD + scol * 8);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(stage + row * STAGE_LD + scol * 8 + 4);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        const bool fullr = (n + 8 <= nout);
-        if (Rf != nullptr) {  // f32 residual (the stream)
-          const float* rptr = Rf + (int64_t)m * p.ldr + n;
-          if (fullr && ((p.ldr & 3) == 0)) {
-            const f32x4 r0 = *reinterpret_cast<const f32x4*>(rptr);
-            const f32x4 r1 = *reinterpret_cast<const f32x4*>(rptr + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[e] += r0[e];
-              v[e + 4] += r1[e];
-            }
-          } else {
-            for (int e = 0; e < 8 && n + e < nout; ++e) v[e] += rptr[e];
-          }
-        } else if (Rg != nullptr) {  // 16-bit residual
-          const T* rptr = Rg + (int64_t)m * p.ldr + n;
-          if (fullr && ((p.ldr & 7) == 0)) {
-            Pack8<T> rv;
-            rv.u = ld_global16(rptr);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += to_f32(rv.e[e]);
-          } else {
-            for (int e = 0; e < 8 && n + e < nout; ++e) v[e] += to_f32(rptr[e]);
-          }
-        }
-        if (want_stats) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (n + e < nout) {
-              cs[e] += v[e];
-              cq[e] = fmaf(v[e], v[e], cq[e]);
-            }
-        }
-        if (out32) {
-          float* cptr = Cf + (int64_t)m * ldc + n;
-          if (fullr && ((ldc & 3) == 0)) {
-            *reinterpret_cast<f32x4*>(cptr) = f32x4{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(cptr + 4) = f32x4{v[4], v[5], v[6], v[7]};
-          } else {
-            for (int e = 0; e < 8 && n + e < nout; ++e) cptr[e] = v[e];
-          }
-        } else {
-          T* cptr = Cg + (int64_t)m * ldc + n;
-          if (fullr && ((ldc & 7) == 0)) {
-            Pack8<T> ov;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ov.e[e] = from_f32<T>(v[e]);
-            st_global16(cptr, ov.u);
-          } else {
-            for (int e = 0; e < 8 && n + e < nout; ++e) cptr[e] = from_f32<T>(v[e]);
-          }
-        }
-      }
-    }
-    __syncthreads();
-    if (want_stats) {  // column sums of these 64 rows: fixed-order sum over the rpp row-lanes (deterministic)
-      float* red = stage;  // [rpp][tw][2]
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        red[((srow * tw) + scol * 8 + e) * 2] = cs[e];
-        red[((srow * tw) + scol * 8 + e) * 2 + 1] = cq[e];
-        cs[e] = cq[e] = 0.f;
-      }
-      __syncthreads();
-      if (tid < tw) {
-        float a = 0.f, b = 0.f;
-        for (int r = 0; r < rpp; ++r) {
-          a += red[(r * tw + tid) * 2];
-          b += red[(r * tw + tid) * 2 + 1];
-        }
-        const int n = nbase + tid;
-        if (n < nout && (mt * WMW + half) * 64 < p.M) {  // (a ragged last tile has no second block)
-          float* dst = p.colstats + (((int64_t)mt * WMW + half) * nout + n) * 2;
-          dst[0] = a;
-          dst[1] = b;
-        }
-      }
-      __syncthreads();
-    }
-  }
+  epilogue_regs<T>(p, acc, bv, m0, n0, wm, wn, fr, fq, mt * WMW + wm, split);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -499,11 +520,11 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const GemmPara
 //   * one raw s_barrier per K-step hands stage k to the consumers and stage k-1 back to the loaders;
 //   * the workgroup is persistent: it walks its share of the (tile, split) list and the loader cursor
 //     runs three K-steps ahead ACROSS tile boundaries, so the next tile streams in during the epilogue;
-//   * the epilogue is wave-private (8 KiB of xor-swizzled f32 scratch per consumer wave, no barrier):
-//     each wave stores its own 64x64 quadrant in whole 256-byte row segments.
-// LDS: 128 KiB ring + 32 KiB scratch = the CU's whole 160 KiB.
+//   * the epilogue is wave-private and LDS-free (epilogue_regs): each consumer wave stores its own 64x64
+//     quadrant straight from the accumulators while the loaders keep streaming.
+// LDS: the 128 KiB ring only (the epilogue works from registers: epilogue_regs).
 constexpr int RING_STAGES = 4;
-constexpr int RING_LDS = RING_STAGES * 2 * TILE_BYTES + 4 * 32 * 64 * 4;
+constexpr int RING_LDS = RING_STAGES * 2 * TILE_BYTES;
 
 template <typename T, int AMODE>
 __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
@@ -556,7 +577,8 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
       l_kt1 = (l_kt + p.ktps < nk_all) ? l_kt + p.ktps : nk_all;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        int n = n0 + 32 * j + 8 * lw + r8;
+        const int pr = 32 * j + 8 * lw + r8;  // LDS row of the W tile -> output column (see epilogue_regs)
+        int n = n0 + cperm(pr, p.act == PM_ACT_GEGLU);
         if (n > p.N - 1) n = p.N - 1;
         b_off[j] = (uint32_t)(((int64_t)n * p.ldw + lc * 8) * 2);
         int m = m0 + 32 * j + 8 * lw + r8;
@@ -684,7 +706,6 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
   // ================= consumer waves =================
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fq = lane >> 4;
-  float* const scr = reinterpret_cast<float*>(smem + RING_STAGES * STAGE_BYTES) + wave * (32 * 64);  // [32][64] f32
   const int a_frag = (wm * 64 + fr) * 128, b_frag = (wn * 64 + fr) * 128;
   const int slot0 = ((fq) ^ (fr & 7)) << 4, slot1 = ((4 + fq) ^ (fr & 7)) << 4;
   const bool partial = p.splits > 1;
@@ -717,14 +738,8 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
     const int m0 = mt * BM, n0 = nt * BN;
     const int kt0 = split * p.ktps;
     const int kt1 = (kt0 + p.ktps < nk_all) ? kt0 + p.ktps : nk_all;
-    // the bias of this wave's columns: requested now, needed in the epilogue
-    const float* bias_p = partial ? nullptr : p.bias;
-    float bv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + fr;
-      bv[j] = (bias_p != nullptr && n < p.N) ? bias_p[n] : 0.f;
-    }
+    float bv[4][4];  // requested now, needed in the epilogue
+    load_bias_regs(p, bv, n0, wn, fq);
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -748,7 +763,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fa0[i].v, fb0[j].v, acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb0[j].v, fa0[i].v, acc[i][j]);
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
@@ -763,7 +778,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fa1[i].v, fb1[j].v, acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb1[j].v, fa1[i].v, acc[i][j]);
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -787,131 +802,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
 #endif
 
     // ---------------- epilogue of this wave's 64x64 quadrant (the loaders keep streaming the next tile) ----
-    const int act = partial ? PM_ACT_NONE : p.act;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] += bv[j];
-    const bool geglu = (act == PM_ACT_GEGLU);
-    if (act == PM_ACT_SILU) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[i][j][r] = silu_f(acc[i][j][r]);
-    } else if (geglu) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[i][jj][r] = acc[i][2 * jj][r] * gelu_erf_f(acc[i][2 * jj + 1][r]);
-    }
-    const int wcols = geglu ? 32 : 64;        // output columns of this wave
-    const int nblk = geglu ? 2 : 4;
-    const int nout = geglu ? (p.N >> 1) : p.N;
-    const int ncol0 = (geglu ? (n0 >> 1) : n0) + wn * wcols;
-    T* __restrict__ Cg = reinterpret_cast<T*>(p.C);
-    const T* __restrict__ Rg = (partial || p.res32) ? nullptr : reinterpret_cast<const T*>(p.R);
-    float* __restrict__ Cf = partial ? p.ws + (int64_t)split * p.M * p.N : reinterpret_cast<float*>(p.C);
-    const float* __restrict__ Rf = (partial || !p.res32) ? nullptr : reinterpret_cast<const float*>(p.R);
-    const bool out32 = partial || p.out32 != 0;
-    const int64_t ldc = partial ? p.N : p.ldc;
-    // store pass: a lane owns 4 consecutive columns; 16 (8: GEGLU) lanes cover a row of the quadrant, so a
-    // wave instruction reads 4 (8) whole scratch rows and stores 4 (8) whole row segments
-    const int lpr = wcols >> 2;
-    const int rpi = 64 / lpr;
-    const int lcol = (lane % lpr) * 4, lrow = lane / lpr;
-    const bool want_stats = (p.colstats != nullptr) && !partial;
-    float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
-    const int n = ncol0 + lcol;
-
-#pragma unroll
-    for (int chunk = 0; chunk < 2; ++chunk) {
-      // scratch row = il*16 + 4*fq + r: the 16-column block index is xor-ed with (row >> 2) & 3 == fq, so
-      // the fq groups of a ds_write_b32 land on different banks without row padding
-#pragma unroll
-      for (int il = 0; il < 2; ++il)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (j < nblk) scr[(il * 16 + 4 * fq + r) * 64 + ((j * 16 + fr) ^ (fq << 4))] = acc[chunk * 2 + il][j][r];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private scratch: LDS ops of one wave are in order
-      for (int rr = lrow; rr < 32; rr += rpi) {
-        const int m = m0 + wm * 64 + chunk * 32 + rr;
-        if (m < p.M && n < nout) {
-          const f32x4 v0 = *reinterpret_cast<const f32x4*>(scr + rr * 64 + (lcol ^ (((rr >> 2) & 3) << 4)));
-          float v[4] = {v0[0], v0[1], v0[2], v0[3]};
-          const bool fullr = (n + 4 <= nout);
-          if (Rf != nullptr) {
-            const float* rptr = Rf + (int64_t)m * p.ldr + n;
-            if (fullr && ((p.ldr & 3) == 0)) {
-              const f32x4 r0 = *reinterpret_cast<const f32x4*>(rptr);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += r0[e];
-            } else {
-              for (int e = 0; e < 4 && n + e < nout; ++e) v[e] += rptr[e];
-            }
-          } else if (Rg != nullptr) {
-            const T* rptr = Rg + (int64_t)m * p.ldr + n;
-            if (fullr && ((p.ldr & 3) == 0)) {
-              Pack4<T> rv;
-              rv.u = *reinterpret_cast<const u32x2*>(rptr);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += to_f32(rv.e[e]);
-            } else {
-              for (int e = 0; e < 4 && n + e < nout; ++e) v[e] += to_f32(rptr[e]);
-            }
-          }
-          if (want_stats) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n + e < nout) {
-                cs[e] += v[e];
-                cq[e] = fmaf(v[e], v[e], cq[e]);
-              }
-          }
-          if (out32) {
-            float* cptr = Cf + (int64_t)m * ldc + n;
-            if (fullr && ((ldc & 3) == 0))
-              *reinterpret_cast<f32x4*>(cptr) = f32x4{v[0], v[1], v[2], v[3]};
-            else
-              for (int e = 0; e < 4 && n + e < nout; ++e) cptr[e] = v[e];
-          } else {
-            T* cptr = Cg + (int64_t)m * ldc + n;
-            if (fullr && ((ldc & 3) == 0)) {
-              Pack4<T> ov;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) ov.e[e] = from_f32<T>(v[e]);
-              *reinterpret_cast<u32x2*>(cptr) = ov.u;
-            } else {
-              for (int e = 0; e < 4 && n + e < nout; ++e) cptr[e] = from_f32<T>(v[e]);
-            }
-          }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    if (want_stats) {  // column sums of this wave's 64 rows: fixed xor tree over the row-lanes (deterministic)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        for (int o = 32; o >= lpr; o >>= 1) {
-          cs[e] += __shfl_xor(cs[e], o, 64);
-          cq[e] += __shfl_xor(cq[e], o, 64);
-        }
-      }
-      if (lane < lpr && (mt * 2 + wm) * 64 < p.M) {  // (a ragged last tile has no second block)
-        float* dst = p.colstats + (((int64_t)mt * 2 + wm) * nout + n) * 2;
-        for (int e = 0; e < 4 && n + e < nout; ++e) {
-          dst[2 * e] = cs[e];
-          dst[2 * e + 1] = cq[e];
-        }
-      }
-    }
+    epilogue_regs<T>(p, acc, bv, m0, n0, wm, wn, fr, fq, mt * 2 + wm, split);
 #ifdef PM_RING_PROF
     t_epi += clock64() - e0;
 #endif
