@@ -233,17 +233,16 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, f32x4 (&acc)[
   }
 }
 
-// BIG = false: 128x128 tile, 4 waves, 2 LDS stages, 2 workgroups per CU (any shape, split-K, f32 A).
-// BIG = true : 256x128 tile, 8 waves, 3 LDS stages of 48 KiB with the DMA of tile t+2 in flight across
-//              the barrier (counted s_waitcnt vmcnt + raw s_barrier): hides the global-load latency that
-//              bounds the 2-stage loop; used when the grid still fills the chip.
-template <typename T, int AMODE, bool A32, bool BIG>
-__global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const GemmParams p) {
-  static_assert(!(BIG && A32), "the big tile is DMA-only");
+// 128x128 tile, 4 waves, 2 LDS stages, 2 workgroups per CU (any shape, split-K, f32 A).  Persistent: a
+// workgroup walks work items slot, slot + G, ... and issues the first K-tile of its NEXT item before the
+// epilogue of the current one, so a tile's first global-load round trip (~2 us of a ~8 us short-K tile)
+// is hidden behind the previous tile's stores.
+template <typename T, int AMODE, bool A32>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   typedef typename std::conditional<A32, float, T>::type TA;  // storage type of the A operand
   constexpr int ES = sizeof(TA);
-  constexpr int NT = BIG ? 512 : 256;        // threads
-  constexpr int WMW = BIG ? 4 : 2;           // waves along M (2 along N)
+  constexpr int NT = 256;                    // threads
+  constexpr int WMW = 2;                     // waves along M (2 along N)
   constexpr int BMT = WMW * 64;              // tile rows
   constexpr int RSTEP = NT / 8;              // rows staged per loader pass
   constexpr int BP = BN / RSTEP;             // loader passes over the W tile (A tile: always 4)
@@ -260,24 +259,24 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const GemmPara
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fq = lane >> 4;
 
-  const int wg0 = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = wg0 % p.splits;
-  const int wg = wg0 / p.splits;
-  // supertile order: workgroups that run together on one XCD (a contiguous run of ids) cover GM row
-  // tiles x several column tiles, so both the A and the W panels they stream stay in that XCD's 4 MiB
-  // L2 (row-major order re-fetched the whole W panel set for every row tile: 9x the algorithmic bytes
-  // on the wide GEGLU GEMM, FETCH_SIZE in profiles/r01/pmc_traffic.md)
-  constexpr int GM = 8;
-  const int grp = wg / (GM * p.ntiles);
-  const int first_m = grp * GM;
-  const int gm = (p.mtiles - first_m < GM) ? p.mtiles - first_m : GM;
-  const int rin = wg - grp * GM * p.ntiles;
-  const int nt = rin / gm;
-  const int mt = first_m + (rin - nt * gm);
-  const int m0 = mt * BMT, n0 = nt * BN;
+  const int G = gridDim.x;
+  const int nwork = p.mtiles * p.ntiles * p.splits;
   const int nk_all = (p.K + BK - 1) / BK;
-  const int kt0 = split * p.ktps;
-  const int kt1 = (kt0 + p.ktps < nk_all) ? kt0 + p.ktps : nk_all;
+  // work item -> (row tile, column tile, K slice).  Supertile order: workgroups that run together on one
+  // XCD (a contiguous run of ids) cover GM row tiles x several column tiles, so both the A and the W
+  // panels they stream stay in that XCD's 4 MiB L2 (row-major order re-fetched the whole W panel set
+  // for every row tile: 9x the algorithmic bytes on the wide GEGLU GEMM, profiles/r01/pmc_traffic.md)
+  auto decode = [&](int w, int& mt, int& nt, int& split) {
+    constexpr int GM = 8;
+    split = w % p.splits;
+    const int wg = w / p.splits;
+    const int grp = wg / (GM * p.ntiles);
+    const int first_m = grp * GM;
+    const int gm = (p.mtiles - first_m < GM) ? p.mtiles - first_m : GM;
+    const int rin = wg - grp * GM * p.ntiles;
+    nt = rin / gm;
+    mt = first_m + (rin - nt * gm);
+  };
 
   const char* const Ab = reinterpret_cast<const char*>(p.A);
   const char* const Wb = reinterpret_cast<const char*>(p.Wt);
@@ -293,49 +292,57 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const GemmPara
   const int lc = (tid & 7) ^ (lr & 7);
   uint32_t b_off[BP], a_off[4];
   int a_y[4], a_x[4];
-#pragma unroll
-  for (int j = 0; j < BP; ++j) {
-    int n = n0 + cperm(lr + RSTEP * j, p.act == PM_ACT_GEGLU);  // LDS row -> output column (epilogue_regs)
-    if (n > p.N - 1) n = p.N - 1;
-    b_off[j] = (uint32_t)(((int64_t)n * p.ldw + lc * 8) * 2);
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int m = m0 + lr + RSTEP * j;
-    if (m > p.M - 1) m = p.M - 1;
-    if (AMODE == A_DENSE) {
-      a_off[j] = (uint32_t)(((int64_t)m * p.lda + lc * 8) * ES);
-      a_y[j] = a_x[j] = 0;
-    } else if (AMODE == A_CONV3X3 || AMODE == A_CONV3X3_FAST) {
-      const int hw = p.Ho * p.Wo;
-      const int f = m / hw;
-      const int rem = m - f * hw;
-      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      a_y[j] = oy * p.stride + 1 - p.pad;  // tap (dy, dx) reads virtual pixel (a_y + dy - 1, a_x + dx - 1)
-      a_x[j] = ox * p.stride + 1 - p.pad;
-      if (AMODE == A_CONV3X3_FAST)  // no upsample: offset of the centre tap, the tap shift is uniform
-        a_off[j] = (uint32_t)((((int64_t)f * p.Hin + a_y[j]) * p.Win + a_x[j]) * p.lda * ES + lc * 8 * ES);
-      else
-        a_off[j] = (uint32_t)((int64_t)f * p.Hin * p.Win * p.lda * ES);
-    } else {
-      const int f = m / p.P;
-      const int pix = m - f * p.P;
-      a_off[j] = (uint32_t)((((int64_t)f * p.P + pix) * p.lda + lc * 8) * ES);
-      a_y[j] = f;
-      a_x[j] = pix;
-    }
-  }
   // (tap, channel) position of the K walk.  Fast modes: one tap per K-tile (Cin % 64 == 0), tracked as
   // wave-uniform scalars.  General conv (stem Cin = 8, nearest-x2 upsample): per-lane.
   int tap_s = 0, ch_s = 0;       // uniform: tap and first channel of the current K-tile
   int tap_l = 0, ch_l = lc * 8;  // per-lane (A_CONV3X3 only)
-  if (AMODE != A_DENSE) {
-    tap_s = (kt0 * BK) / p.Cin;
-    ch_s = kt0 * BK - tap_s * p.Cin;
-    const int k_l = kt0 * BK + lc * 8;
-    tap_l = k_l / p.Cin;
-    ch_l = k_l - tap_l * p.Cin;
-  }
+  // point the loader at work item w; returns its first K-tile
+  auto loader_begin = [&](int w) -> int {
+    int mt, nt, split;
+    decode(w, mt, nt, split);
+    const int m0 = mt * BMT, n0 = nt * BN;
+    const int kt0 = split * p.ktps;
+#pragma unroll
+    for (int j = 0; j < BP; ++j) {
+      int n = n0 + cperm(lr + RSTEP * j, p.act == PM_ACT_GEGLU);  // LDS row -> output column (epilogue_regs)
+      if (n > p.N - 1) n = p.N - 1;
+      b_off[j] = (uint32_t)(((int64_t)n * p.ldw + lc * 8) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int m = m0 + lr + RSTEP * j;
+      if (m > p.M - 1) m = p.M - 1;
+      if (AMODE == A_DENSE) {
+        a_off[j] = (uint32_t)(((int64_t)m * p.lda + lc * 8) * ES);
+        a_y[j] = a_x[j] = 0;
+      } else if (AMODE == A_CONV3X3 || AMODE == A_CONV3X3_FAST) {
+        const int hw = p.Ho * p.Wo;
+        const int f = m / hw;
+        const int rem = m - f * hw;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        a_y[j] = oy * p.stride + 1 - p.pad;  // tap (dy, dx) reads virtual pixel (a_y + dy - 1, a_x + dx - 1)
+        a_x[j] = ox * p.stride + 1 - p.pad;
+        if (AMODE == A_CONV3X3_FAST)  // no upsample: offset of the centre tap, the tap shift is uniform
+          a_off[j] = (uint32_t)((((int64_t)f * p.Hin + a_y[j]) * p.Win + a_x[j]) * p.lda * ES + lc * 8 * ES);
+        else
+          a_off[j] = (uint32_t)((int64_t)f * p.Hin * p.Win * p.lda * ES);
+      } else {
+        const int f = m / p.P;
+        const int pix = m - f * p.P;
+        a_off[j] = (uint32_t)((((int64_t)f * p.P + pix) * p.lda + lc * 8) * ES);
+        a_y[j] = f;
+        a_x[j] = pix;
+      }
+    }
+    if (AMODE != A_DENSE) {
+      tap_s = (kt0 * BK) / p.Cin;
+      ch_s = kt0 * BK - tap_s * p.Cin;
+      const int k_l = kt0 * BK + lc * 8;
+      tap_l = k_l / p.Cin;
+      ch_l = k_l - tap_l * p.Cin;
+    }
+    return kt0;
+  };
 
   u32x4 ra[4], ra_hi[4], rb[BP];  // register staging (A32 only); ra_hi: second half of an f32 chunk
   // issue the loads of K-tile kt (tiles are requested in increasing order) into LDS buffer `buf`
@@ -434,75 +441,70 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const GemmPara
     }
   };
 
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bv[4][4];  // bias of this lane's columns: requested now, needed in the epilogue
-  load_bias_regs(p, bv, n0, wn, fq);
-
   // fragment read offsets: row & 7 == fr & 7 for every MFMA block of this wave, so the swizzled slot
   // depends on the k-step only; the block index becomes an immediate offset of the ds_read_b128
   const int a_frag = (wm * 64 + fr) * 128, b_frag = (wn * 64 + fr) * 128;
   const int slot0 = ((fq) ^ (fr & 7)) << 4, slot1 = ((4 + fq) ^ (fr & 7)) << 4;
 
+  int w = xcd_remap(blockIdx.x, G);  // (G <= nwork: every workgroup has a first item)
   int buf = 0;
-  if constexpr (BIG) {
-    load_tile(kt0, 0);
-    if (kt0 + 1 < kt1) load_tile(kt0 + 1, 1);
-  } else {
-    load_tile(kt0, 0);
-    store_tile(0);
-    __syncthreads();  // (hipcc drains vmcnt before the barrier, so the DMA'd tile is visible)
-  }
+  load_tile(loader_begin(w), 0);
+  store_tile(0);
+  __syncthreads();  // (hipcc drains vmcnt before the barrier, so the DMA'd tile is visible)
 
-  for (int kt = kt0; kt < kt1; ++kt) {
-    if constexpr (BIG) {
-      // tile kt landed once at most the 6 DMAs of tile kt+1 are still outstanding (vmcnt counts in
-      // issue order); the barrier then (a) publishes every wave's part of tile kt and (b) proves that
-      // all waves finished reading stage (kt-1)%3, which the DMA of tile kt+2 issued below overwrites
+  for (;;) {
+    int mt, nt, split;
+    decode(w, mt, nt, split);
+    const int m0 = mt * BMT, n0 = nt * BN;
+    const int kt0 = split * p.ktps;
+    const int kt1 = (kt0 + p.ktps < nk_all) ? kt0 + p.ktps : nk_all;
+    const bool has_next = (w + G < nwork);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bv[4][4];  // bias of this lane's columns: requested now, needed in the epilogue
+    load_bias_regs(p, bv, n0, wn, fq);
+
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const bool more = (kt + 1 < kt1) || has_next;
       if (kt + 1 < kt1)
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (kt + 2 < kt1) load_tile(kt + 2, buf >= 1 ? buf - 1 : 2);
-    } else {
-      if (kt + 1 < kt1) load_tile(kt + 1, buf ^ 1);
-    }
-    const char* as = As + buf * STAGE_BYTES + a_frag;
-    const char* bs = Bs + buf * STAGE_BYTES + b_frag;
-    // all 16 fragment reads of the K-tile are issued first (64 VGPRs), so the MFMAs of k-step 0 start
-    // as soon as ITS operands land and the reads of k-step 1 are hidden behind them; written per
-    // k-step the compiler serialises read -> lgkmcnt(0) -> MFMA four times per tile
-    Pack8<T> a[2][4], b[2][4];
+        load_tile(kt + 1, buf ^ 1);
+      else if (has_next)  // first K-tile of the next work item: in flight during this item's epilogue
+        load_tile(loader_begin(w + G), buf ^ 1);
+      const char* as = As + buf * STAGE_BYTES + a_frag;
+      const char* bs = Bs + buf * STAGE_BYTES + b_frag;
+      // all 16 fragment reads of the K-tile are issued first (64 VGPRs), so the MFMAs of k-step 0 start
+      // as soon as ITS operands land and the reads of k-step 1 are hidden behind them; written per
+      // k-step the compiler serialises read -> lgkmcnt(0) -> MFMA four times per tile
+      Pack8<T> a[2][4], b[2][4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int slot = ks ? slot1 : slot0;
+      for (int ks = 0; ks < 2; ++ks) {
+        const int slot = ks ? slot1 : slot0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[ks][i].u = *reinterpret_cast<const u32x4*>(as + i * 2048 + slot);
+        for (int i = 0; i < 4; ++i) a[ks][i].u = *reinterpret_cast<const u32x4*>(as + i * 2048 + slot);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[ks][j].u = *reinterpret_cast<const u32x4*>(bs + j * 2048 + slot);
-    }
+        for (int j = 0; j < 4; ++j) b[ks][j].u = *reinterpret_cast<const u32x4*>(bs + j * 2048 + slot);
+      }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(b[ks][j].v, a[ks][i].v, acc[i][j]);  // C^T: see epilogue_regs
-    }
-    if constexpr (BIG) {
-      buf = (buf == 2) ? 0 : buf + 1;
-    } else {
-      if (kt + 1 < kt1) store_tile(buf ^ 1);
+          for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(b[ks][j].v, a[ks][i].v, acc[i][j]);  // C^T: see epilogue_regs
+      }
+      if (more) store_tile(buf ^ 1);
       __syncthreads();
       buf ^= 1;
     }
+    // ---------------- epilogue: registers -> global (no LDS staging, no barrier) ----------------
+    // split-K slices store raw f32 partials into their slab; bias/act/residual run in the reduce pass
+    epilogue_regs<T>(p, acc, bv, m0, n0, wm, wn, fr, fq, mt * WMW + wm, split);
+    if (!has_next) break;
+    w += G;
   }
-  // ---------------- epilogue: registers -> global (no LDS staging, no barrier) ----------------
-  // split-K slices store raw f32 partials into their slab; bias/act/residual run in the reduce pass
-  epilogue_regs<T>(p, acc, bv, m0, n0, wm, wn, fr, fq, mt * WMW + wm, split);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -855,7 +857,7 @@ static int g_num_cus = 0;
 #ifdef PM_RING_PROF
 static long long* g_ring_prof = nullptr;
 #endif
-static bool g_allow_big = false;  // PANDORA_GEMM_BIG=1 enables the 256x128 tile (measured: no gain yet)
+static int g_persist = 0;  // PANDORA_GEMM_PERSIST = r > 0: cap the 2-stage kernel's grid at r x 2 workgroups per CU (persistent walk with cross-tile prefetch; measured: no gain over one item per workgroup, so off)
 static int g_split_min_nk = 24;     // PANDORA_SPLITK_MIN_NK: shortest K loop (in 64-wide tiles) that is split
 
 static int choose_splits(int64_t M, int64_t N, int64_t K, int act, int* ktps) {
@@ -873,8 +875,8 @@ static int choose_splits(int64_t M, int64_t N, int64_t K, int act, int* ktps) {
 
 static void plan_split(GemmParams& p, void* workspace, size_t workspace_bytes) {
   static const bool init = [] {
-    const char* e = getenv("PANDORA_GEMM_BIG");
-    g_allow_big = (e && e[0] == '1');
+    const char* e = getenv("PANDORA_GEMM_PERSIST");
+    if (e) g_persist = atoi(e);
     const char* m = getenv("PANDORA_SPLITK_MIN_NK");
     if (m) g_split_min_nk = atoi(m);
     const char* r = getenv("PANDORA_GEMM_RING");
@@ -899,20 +901,30 @@ static void plan_split(GemmParams& p, void* workspace, size_t workspace_bytes) {
   p.ws = reinterpret_cast<float*>(workspace);
 }
 
-template <typename T, int AMODE, bool A32, bool BIG> static int launch1(const GemmParams& p, hipStream_t stream) {
-  constexpr int bm = BIG ? 256 : BM;
-  constexpr int nt = BIG ? 512 : 256;
-  constexpr int lds = BIG ? 3 * (256 + BN) * BK * 2 : 4 * TILE_BYTES;
+static int num_cus() {
+  if (g_num_cus == 0) {
+    int dev = 0, n = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    g_num_cus = n;
+  }
+  return g_num_cus;
+}
+
+template <typename T, int AMODE, bool A32> static int launch1(const GemmParams& p, hipStream_t stream) {
+  constexpr int lds = 4 * TILE_BYTES;
   GemmParams q = p;
-  q.mtiles = (p.M + bm - 1) / bm;
-  const int grid = q.mtiles * p.ntiles * p.splits;
+  q.mtiles = (p.M + BM - 1) / BM;
+  const int64_t nwork = (int64_t)q.mtiles * p.ntiles * p.splits;
+  const int64_t slots = 2 * (int64_t)num_cus() * g_persist;  // 2 workgroups per CU; g_persist = 0: one item each
+  const int grid = (int)((g_persist == 0 || nwork < slots) ? nwork : slots);
   static bool attr_set = false;  // idempotent; a benign race sets the same value twice
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, AMODE, A32, BIG>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, AMODE, A32>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<T, AMODE, A32, BIG>), dim3(grid), dim3(nt), lds, stream, q);
+  hipLaunchKernelGGL((gemm_kernel<T, AMODE, A32>), dim3(grid), dim3(256), lds, stream, q);
   if (p.splits > 1) {
     const int64_t work = (int64_t)p.M * ((p.N + 3) / 4);
     int64_t nb = (work + 255) / 256;
@@ -923,19 +935,13 @@ template <typename T, int AMODE, bool A32, bool BIG> static int launch1(const Ge
 }
 
 template <typename T, int AMODE> static int launch_ring(const GemmParams& p, hipStream_t stream) {
-  if (g_num_cus == 0) {
-    int dev = 0, n = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-    g_num_cus = n;
-  }
   GemmParams q = p;
 #ifdef PM_RING_PROF
   q.prof = g_ring_prof;
 #endif
   q.mtiles = (p.M + BM - 1) / BM;
   const int64_t nwork = (int64_t)q.mtiles * p.ntiles * p.splits;
-  const int grid = (int)(nwork < g_num_cus ? nwork : g_num_cus);
+  const int grid = (int)(nwork < num_cus() ? nwork : num_cus());
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<T, AMODE>),
@@ -953,15 +959,12 @@ template <typename T, int AMODE> static int launch_ring(const GemmParams& p, hip
 }
 
 template <typename T, int AMODE> static int launch(const GemmParams& p, int flags, hipStream_t stream) {
-  if (flags & PM_FLAG_A_F32) return launch1<T, AMODE, true, false>(p, stream);
+  if (flags & PM_FLAG_A_F32) return launch1<T, AMODE, true>(p, stream);
   if constexpr (AMODE != A_CONV3X3) {
     const int64_t nwork = (int64_t)((p.M + BM - 1) / BM) * p.ntiles * p.splits;
     if (g_ring == 2 || (g_ring == 1 && nwork <= g_ring_max_work)) return launch_ring<T, AMODE>(p, stream);
   }
-  // big tile when it still yields at least one workgroup per CU (and no split-K, no K tail)
-  const int64_t big_tiles = (int64_t)((p.M + 255) / 256) * p.ntiles;
-  if (AMODE != A_CONV3X3 && p.splits == 1 && big_tiles >= 256 && g_allow_big) return launch1<T, AMODE, false, true>(p, stream);
-  return launch1<T, AMODE, false, false>(p, stream);
+  return launch1<T, AMODE, false>(p, stream);
 }
 
 // the loaders address an operand as (64-bit uniform base) + (32-bit lane byte offset)

@@ -391,11 +391,11 @@ def test_splitk_matches_unsplit_and_oracle(hip_ops_factory, dtype):
     assert rel_err(got, want) <= TOL[dtype]
 
 
-# ---- 256x128 big-tile path (3-stage DMA pipeline): needs >= 256 big tiles, i.e. large M ----------
+# ---- full-size M: the persistent grid (several work items per workgroup, cross-tile prefetch) ----------
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_large_m_gemm_conv_tconv(hip_ops_factory, dtype):
     """Full-size M (40960 rows).  Also the shapes that take the optional 256x128 3-stage tile
-    (PANDORA_GEMM_BIG=1, run by tools/ab_gemm.sh; off by default: measured no faster)."""
+    are the grids of more than 2 x 256 tiles on which a workgroup walks several work items."""
     ops = hip_ops_factory(dtype)
     # dense: M = 40960 (+ ragged tail), N = 320 (2.5 column tiles), K = 320 and 1280, every epilogue
     M = 40960 + 77
