@@ -48,6 +48,7 @@ extern "C" {
 #define PM_ACT_NONE 0
 #define PM_ACT_SILU 1
 #define PM_ACT_GEGLU 2 /* weight rows interleaved x/gate in blocks of 16 (see pm_gemm) */
+#define PM_ACT_GELU 3  /* erf GELU (nn.GELU default): the image Resampler's feed-forward, resampler.py:27-34 */
 
 const char* pm_strerror(int code);
 int pm_abi_version(void);

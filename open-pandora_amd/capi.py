@@ -11,8 +11,8 @@ LIB_PATH = os.environ.get("PANDORA_LIB", os.path.join(HERE, "libpandora_mi355x.s
 
 PM_F16, PM_BF16, PM_F32 = 1, 2, 3
 PM_FLAG_A_F32, PM_FLAG_OUT_F32, PM_FLAG_RES_F32 = 1, 2, 4
-PM_ACT_NONE, PM_ACT_SILU, PM_ACT_GEGLU = 0, 1, 2
-ACT_CODES = {"none": PM_ACT_NONE, None: PM_ACT_NONE, "silu": PM_ACT_SILU, "geglu": PM_ACT_GEGLU}
+PM_ACT_NONE, PM_ACT_SILU, PM_ACT_GEGLU, PM_ACT_GELU = 0, 1, 2, 3
+ACT_CODES = {"none": PM_ACT_NONE, None: PM_ACT_NONE, "silu": PM_ACT_SILU, "geglu": PM_ACT_GEGLU, "gelu": PM_ACT_GELU}
 
 # name -> (restype, argtypes); mirrors include/pandora_mi355x.h declaration by declaration
 SIGNATURES = {

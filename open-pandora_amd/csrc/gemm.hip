@@ -151,6 +151,9 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, f32x4 (&acc)[
           if (act == PM_ACT_SILU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+          } else if (act == PM_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
           }
           const bool fullr = (n + 8 <= nout);
           if (Rf != nullptr) {
@@ -841,6 +844,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
     for (int e = 0; e < 4 && n + e < p.N; ++e) {
       float x = v[e] + (p.bias ? p.bias[n + e] : 0.f);
       if (p.act == PM_ACT_SILU) x = silu_f(x);
+      if (p.act == PM_ACT_GELU) x = gelu_erf_f(x);
       if (p.R) x += p.res32 ? reinterpret_cast<const float*>(p.R)[m * p.ldr + n + e]
                             : to_f32(reinterpret_cast<const T*>(p.R)[m * p.ldr + n + e]);
       if (p.out32)
@@ -978,7 +982,7 @@ static int check_common(const void* A, const void* W, void* C, int64_t M, int64_
   if (M < 1 || N < 1 || K < 8 || (K & 7)) return PM_E_SHAPE;
   if (M > (1ll << 30) || N > (1ll << 30) || K > (1ll << 30)) return PM_E_SHAPE;
   if (act == PM_ACT_GEGLU && (N % 32) != 0) return PM_E_SHAPE;
-  if (act < PM_ACT_NONE || act > PM_ACT_GEGLU) return PM_E_SHAPE;
+  if (act < PM_ACT_NONE || act > PM_ACT_GELU) return PM_E_SHAPE;
   return PM_OK;
 }
 

@@ -7,8 +7,10 @@ world-model driver (model.py), restated around the MI355X path:
   multi-round stitching         model.py:1094-1129, 1199-1211
 
 What is NOT here (out of scope for this tier): the ChatUniVi LLM + QFormer that produce
-`diffusion_conditioning`, the OpenCLIP image tower + Resampler that produce the image tokens, and the
-AutoencoderKL.  They enter as callables / tensors: `embed_image(img) -> (1, 256, 1024)` tokens,
+`diffusion_conditioning` and the OpenCLIP image tower.  The Resampler behind the tower is
+`open_pandora_amd.resampler.Resampler` (§8f row 2; `ImageContext` below chains tower -> Resampler and
+caches the input-independent unconditional tokens), the AutoencoderKL is `open_pandora_amd.autoencoder`.
+They enter as callables / tensors: `embed_image(img) -> (1, 256, 1024)` tokens,
 `uncond_text -> (1, 77, 1024)`, `encode_first_stage`, `decode_first_stage`; with `decode_first_stage=None`
 the latents are returned (that is what bench.py and the parity tests consume).
 """
@@ -65,6 +67,25 @@ def image_guided_synthesis(diffusion_model, diffusion_conditioning, img_emb, uc_
     return torch.stack(variants).permute(1, 0, 2, 3, 4, 5)
 
 
+class ImageContext:
+    """`embedder` (the OpenCLIP image tower, condition.py:300-382: img -> (b, 257, 1280) tokens) followed by
+    the Resampler (`image_proj_model`, model.py:711-712).  The unconditional image tokens are the tokens of
+    an all-zero image (model.py:728-729): input-independent, so computed once per image shape and cached."""
+
+    def __init__(self, embedder, image_proj_model):
+        self.embedder, self.image_proj_model = embedder, image_proj_model
+        self._uncond = {}
+
+    def __call__(self, img):
+        return self.image_proj_model(self.embedder(img))
+
+    def uncond(self, img):
+        key = (tuple(img.shape), img.dtype, str(img.device))
+        if key not in self._uncond:
+            self._uncond[key] = self(torch.zeros_like(img))
+        return self._uncond[key]
+
+
 class DiffusionRunner:
     """The part of WorldModel.generate / ChatWM that drives the denoiser (model.py:783-816, 989-1129)."""
 
@@ -88,7 +109,8 @@ class DiffusionRunner:
         h, w = diffusion_pixel_values.shape[-2:]
         z = get_latent_z(self.encode_first_stage, diffusion_pixel_values[None, ...])
         img_emb = self.embed_image(diffusion_cond_image)
-        uc_img_emb = self.embed_image(torch.zeros_like(diffusion_cond_image))
+        uncond = getattr(self.embed_image, "uncond", None)  # ImageContext caches the zero-image tokens
+        uc_img_emb = uncond(diffusion_cond_image) if uncond else self.embed_image(torch.zeros_like(diffusion_cond_image))
         T = self.diffusion_model.temporal_length
         return image_guided_synthesis(self.diffusion_model, diffusion_conditioning[-1:], img_emb, self.uncond_text_emb,
                                       uc_img_emb, z, [1, 4, T, h // 8, w // 8], sampler=self.sampler,

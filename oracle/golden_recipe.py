@@ -11,6 +11,12 @@ UNET_SMALL_CASES = (("mc64_8x8_t500", 64, 8, 8, 500, 15), ("mc64_8x16_t999", 64,
 DDIM_SMALL_CASES = ((5, 0.0, 4.0), (10, 0.0, 4.0), (20, 1.0, 4.0), (10, 0.0, 1.0), (10, 1.0, 4.0))
 DDIM_RESCALE_CASES = ((5, 0.0, 4.0, 0.7), (20, 1.0, 7.5, 0.3))  # (S, eta, cfg, guidance_rescale)
 
+# (tag, constructor kwargs, x shape): a reduced Resampler and the shipped image_proj_stage_config
+RESAMPLER_CASES = (("small", dict(dim=128, depth=2, dim_head=64, heads=2, num_queries=4, embedding_dim=192,
+                                   output_dim=128, ff_mult=4, video_length=4), (2, 17, 192)),
+                   ("full", dict(dim=1024, depth=4, dim_head=64, heads=12, num_queries=16, embedding_dim=1280,
+                                 output_dim=1024, ff_mult=4, video_length=16), (1, 257, 1280)))
+
 
 def module_input(name, *shape):
     return (synth.uniform_pm1(int(np.prod(shape)), INPUT_SEED, name) * 3 ** 0.5).reshape(*shape)

@@ -155,6 +155,26 @@ def gen_ddim_rescale():
     save("ddim_small_rescale.npz", **out)
 
 
+def gen_resampler():
+    """The real Resampler (resampler.py:96-144) on seeded weights: reduced config in full, the shipped
+    image_proj_stage_config (inference_512_v1.0.yaml:91-102) as a digest."""
+    rh._install_shims()
+    from lvdm.modules.encoders.resampler import Resampler
+    out = {}
+    for tag, kw, xs in gr.RESAMPLER_CASES:
+        m = Resampler(**kw)
+        m.load_state_dict(synth.synth_state_dict(m, seed=WEIGHT_SEED))
+        x = gr.module_input(f"resampler/{tag}", *xs)
+        with torch.no_grad():
+            y = m(x)
+        if tag == "small":
+            out["small"] = y.numpy()
+        else:
+            for k, v in digest(y, n=8192).items():
+                out[f"{tag}/{k}"] = v
+    save("resampler.npz", **out)
+
+
 def gen_full(traj):
     torch.set_num_threads(os.cpu_count() or 8)
     t0 = time.time()
@@ -244,7 +264,12 @@ if __name__ == "__main__":
     ap.add_argument("--oracle-72x128", action="store_true")
     ap.add_argument("--ae", action="store_true")
     ap.add_argument("--rescale", action="store_true")
+    ap.add_argument("--resampler", action="store_true")
     a = ap.parse_args()
+    if a.resampler:
+        assert rh.available()
+        gen_resampler()
+        sys.exit(0)
     if a.rescale:
         assert rh.available()
         gen_ddim_rescale()

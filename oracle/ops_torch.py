@@ -55,6 +55,8 @@ class TorchOps:
             y = y + _f(bias)
         if act == "silu":
             y = F_.silu(y)
+        elif act == "gelu":
+            y = F_.gelu(y)
         elif act == "geglu":
             # packed rows: per 32-row group [16 value rows | 16 gate rows]
             n = y.shape[1]

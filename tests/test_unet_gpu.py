@@ -79,6 +79,23 @@ def test_ddim_guidance_rescale_trajectory(hip_ops_factory, dtype, S, eta, cfg, g
     assert err <= TRAJ_TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("tag,kw,xs", gr.RESAMPLER_CASES, ids=[c[0] for c in gr.RESAMPLER_CASES])
+def test_resampler_gpu(hip_ops_factory, dtype, tag, kw, xs):
+    """Image-context Resampler on the HIP kernels vs the real reference module (f32 CPU)."""
+    from open_pandora_amd.resampler import Resampler
+    g = load("resampler.npz")
+    m = Resampler(**kw)
+    m.load_state_dict(synth.synth_state_dict(m, seed=gr.WEIGHT_SEED))
+    y = m.bind(hip_ops_factory(dtype))(gr.module_input(f"resampler/{tag}", *xs).cuda()).float().cpu()
+    if tag == "small":
+        err = rel(y, g["small"])
+    else:
+        err = rel(gr.digest_of(y, g[f"{tag}/stride"], len(g[f"{tag}/slice"])), g[f"{tag}/slice"])
+    print(f"\n[parity] resampler {tag} {dtype}: rel err {err:.2e}")
+    assert err <= FWD_TOL[dtype]
+
+
 def _digest_err(t, g, prefix):
     sl = gr.digest_of(t.cpu(), g[f"{prefix}/stride"], len(g[f"{prefix}/slice"]))
     return rel(sl, g[f"{prefix}/slice"]), float(t.float().std()), float(g[f"{prefix}/std"])
