@@ -9,7 +9,7 @@ WEIGHT_SEED, INPUT_SEED, NOISE_SEED = 20230211, 123, 7
 UNET_SMALL_CASES = (("mc64_8x8_t500", 64, 8, 8, 500, 15), ("mc64_8x16_t999", 64, 8, 16, 999, 24),
                     ("mc128_8x8_t37", 128, 8, 8, 37, 3))
 DDIM_SMALL_CASES = ((5, 0.0, 4.0), (10, 0.0, 4.0), (20, 1.0, 4.0), (10, 0.0, 1.0), (10, 1.0, 4.0))
-DDIM_RESCALE_CASES = ((5, 0.0, 4.0, 0.7), (20, 1.0, 7.5, 0.3))  # (S, eta, cfg, guidance_rescale)
+DDIM_RESCALE_CASES = ((5, 0.0, 4.0, 0.7), (20, 1.0, 4.0, 0.3))  # (S, eta, cfg, guidance_rescale)
 
 # (tag, constructor kwargs, x shape): a reduced Resampler and the shipped image_proj_stage_config
 RESAMPLER_CASES = (("small", dict(dim=128, depth=2, dim_head=64, heads=2, num_queries=4, embedding_dim=192,
