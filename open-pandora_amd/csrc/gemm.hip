@@ -87,6 +87,95 @@ __device__ __forceinline__ void load_bias_regs(const GemmParams& p, float (&bv)[
       bv[j][r] = (bias_p != nullptr && n < p.N) ? bias_p[n] : 0.f;
     }
 }
+// Straight-line store pass of one epilogue flavour (OUT32: f32 output; RES: 0 none, 1 16-bit, 2 f32 residual).
+// The generic epilogue below carries every flavour behind runtime branches, replicated 8x by the unrolled
+// (row block, column pair) loops: ~6000 cycles per tile by the in-kernel stamps (branch-bound and far beyond
+// the instruction cache).  Here the flavour is chosen ONCE per tile, addresses of dead lanes are clamped
+// (so the residual loads of a half tile issue back to back, unconditionally) and only the stores are
+// predicated.  Needs N % 8 == 0 and 16-byte-aligned rows (checked by the caller).
+template <typename T, bool OUT32, int RES>
+__device__ __forceinline__ void store_fast(const GemmParams& p, f32x4 (&acc)[4][4], void* cbase, int64_t ldc,
+                                           int mrow0, int ncol0, int nout, int fr, int fq, bool stats,
+                                           float (&cs)[2][8], float (&cq)[2][8]) {
+  int ncl[2];
+  bool nok[2];
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp) {
+    const int n = ncol0 + jp * 32 + fq * 8;
+    nok[jp] = n < nout;
+    ncl[jp] = nok[jp] ? n : 0;
+  }
+#pragma unroll
+  for (int ih = 0; ih < 2; ++ih) {  // two row-block halves: bounds the residual registers in flight
+    u32x4 r16[2][2];
+    f32x4 r32[2][2][2];
+    int64_t rowoff[2];
+    bool mok[2];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const int m = mrow0 + (ih * 2 + ii) * 16 + fr;
+      mok[ii] = m < p.M;
+      rowoff[ii] = mok[ii] ? m : 0;
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        if constexpr (RES == 1) {
+          r16[ii][jp] = ld_global16(reinterpret_cast<const T*>(p.R) + rowoff[ii] * p.ldr + ncl[jp]);
+        } else if constexpr (RES == 2) {
+          const float* rp = reinterpret_cast<const float*>(p.R) + rowoff[ii] * p.ldr + ncl[jp];
+          r32[ii][jp][0] = *reinterpret_cast<const f32x4*>(rp);
+          r32[ii][jp][1] = *reinterpret_cast<const f32x4*>(rp + 4);
+        }
+      }
+    }
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const int i = ih * 2 + ii;
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[i][2 * jp][r];
+          v[4 + r] = acc[i][2 * jp + 1][r];
+        }
+        if constexpr (RES == 1) {
+          Pack8<T> rv;
+          rv.u = r16[ii][jp];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += to_f32(rv.e[e]);
+        } else if constexpr (RES == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] += r32[ii][jp][0][e];
+            v[e + 4] += r32[ii][jp][1][e];
+          }
+        }
+        const bool ok = mok[ii] && nok[jp];
+        if (stats) {  // (wave-uniform)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = ok ? v[e] : 0.f;
+            cs[jp][e] += x;
+            cq[jp][e] = fmaf(x, x, cq[jp][e]);
+          }
+        }
+        if (ok) {
+          if constexpr (OUT32) {
+            float* cptr = reinterpret_cast<float*>(cbase) + rowoff[ii] * ldc + ncl[jp];
+            *reinterpret_cast<f32x4*>(cptr) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(cptr + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          } else {
+            Pack8<T> ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov.e[e] = from_f32<T>(v[e]);
+            st_global16(reinterpret_cast<T*>(cbase) + rowoff[ii] * ldc + ncl[jp], ov.u);
+          }
+        }
+      }
+    }
+  }
+}
+
 // rows m0 + wm*64 + i*16 + fr, columns n0 + wn*64 + ...; sblock = index of this wave's 64-row block in colstats
 template <typename T>
 __device__ __forceinline__ void epilogue_regs(const GemmParams& p, f32x4 (&acc)[4][4], const float (&bv)[4][4],
@@ -108,6 +197,76 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, f32x4 (&acc)[
   const bool out32 = partial || p.out32 != 0;
   const int64_t ldc = partial ? p.N : p.ldc;
   const bool want_stats = (p.colstats != nullptr) && !partial;
+  // ---- fast flavours (every shape of the U-Net except N % 8 != 0, i.e. the 4-channel output conv) ----
+  if (!geglu && (nout & 7) == 0 && (ldc & 7) == 0 && (p.R == nullptr || (p.ldr & 7) == 0)) {
+    // bias and activation in place (one uniform branch per activation, not per element group)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] += bv[j][r];
+    if (act == PM_ACT_SILU) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = silu_f(acc[i][j][r]);
+    } else if (act == PM_ACT_GELU) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = gelu_erf_f(acc[i][j][r]);
+    }
+    float cs[2][8], cq[2][8];
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cs[jp][e] = cq[jp][e] = 0.f;
+    const int mrow0 = m0 + wm * 64, ncol0 = n0 + wn * 64;
+    void* cb = out32 ? static_cast<void*>(Cf) : static_cast<void*>(Cg);
+    if (out32) {
+      if (Rf != nullptr)
+        store_fast<T, true, 2>(p, acc, cb, ldc, mrow0, ncol0, nout, fr, fq, want_stats, cs, cq);
+      else
+        store_fast<T, true, 0>(p, acc, cb, ldc, mrow0, ncol0, nout, fr, fq, want_stats, cs, cq);
+    } else {
+      if (Rf != nullptr)
+        store_fast<T, false, 2>(p, acc, cb, ldc, mrow0, ncol0, nout, fr, fq, want_stats, cs, cq);
+      else if (Rg != nullptr)
+        store_fast<T, false, 1>(p, acc, cb, ldc, mrow0, ncol0, nout, fr, fq, want_stats, cs, cq);
+      else
+        store_fast<T, false, 0>(p, acc, cb, ldc, mrow0, ncol0, nout, fr, fq, want_stats, cs, cq);
+    }
+    if (want_stats) {  // column sums of this wave's 64 rows: in-lane over i, then a fixed xor tree over fr
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) {
+            cs[jp][e] += __shfl_xor(cs[jp][e], o, 64);
+            cq[jp][e] += __shfl_xor(cq[jp][e], o, 64);
+          }
+        }
+      if (fr == 0 && sblock * 64 < p.M) {  // (a ragged last tile has no second block)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          const int n = ncol0 + jp * 32 + fq * 8;
+          if (n < nout) {
+            float* dst = p.colstats + ((int64_t)sblock * nout + n) * 2;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2)
+              *reinterpret_cast<f32x4*>(dst + 2 * e) = f32x4{cs[jp][e], cq[jp][e], cs[jp][e + 1], cq[jp][e + 1]};
+          }
+        }
+      }
+    }
+    return;
+  }
   if (geglu) {
     // value block 2jj, gate block 2jj+1 (weights packed [16 value | 16 gate]): 4 output columns per lane
 #pragma unroll
@@ -855,8 +1014,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
   }
 }
 
-static int g_ring = 1;  // PANDORA_GEMM_RING: 0 = never, 1 = where the grid is at most g_ring_max_work, 2 = always
-static int g_ring_max_work = 256;  // one round: at most one tile per CU (measured: the 2-stage kernel wins once CUs hold 2 tiles)
+static int g_ring = 1;  // PANDORA_GEMM_RING: 0 = never, 1 = by prefer_ring(), 2 = always
+static int g_ring_max_work = 0;  // PANDORA_GEMM_RING_MAX_WORK > 0: never use the ring kernel above that many work items
 static int g_num_cus = 0;
 #ifdef PM_RING_PROF
 static long long* g_ring_prof = nullptr;
@@ -962,11 +1121,27 @@ template <typename T, int AMODE> static int launch_ring(const GemmParams& p, hip
   return check_launch();
 }
 
+// Which kernel for a 16-bit-operand call (measured per shape in the model, tools/shape_profile.py with
+// PANDORA_GEMM_RING=0 / 2).  The ring kernel has the faster steady state (~700 vs ~950 cycles per K-step per
+// CU) and hides the load round trip, but owns the CU alone: it pays for every epilogue with idle MFMA time and
+// quantises the grid in rounds of 1 workgroup per CU, where the 2-stage kernel runs rounds of 2.
+static bool prefer_ring(int amode, const GemmParams& p) {
+  if (p.act == PM_ACT_GEGLU) return false;  // erf-heavy epilogue: wants a co-resident workgroup to hide it
+  const int64_t nwork = (int64_t)((p.M + BM - 1) / BM) * p.ntiles * p.splits;
+  if (g_ring_max_work > 0 && nwork > g_ring_max_work) return false;
+  const int64_t cu = num_cus();
+  const double eff_ring = (double)nwork / (double)(((nwork + cu - 1) / cu) * cu);
+  const double eff_two = (double)nwork / (double)(((nwork + 2 * cu - 1) / (2 * cu)) * 2 * cu);
+  if (amode == A_CONVT3) return eff_ring > eff_two + 0.05 || (nwork <= cu && nwork >= cu / 2);
+  if (nwork <= cu) return true;  // one tile per CU: the 2-stage kernel would be round-trip-bound
+  if (amode == A_CONV3X3_FAST) return eff_ring >= eff_two;  // long K loops: ties go to the faster steady state
+  return (p.M <= 2560 && p.splits == 1) || eff_ring > eff_two + 0.05;
+}
+
 template <typename T, int AMODE> static int launch(const GemmParams& p, int flags, hipStream_t stream) {
   if (flags & PM_FLAG_A_F32) return launch1<T, AMODE, true>(p, stream);
   if constexpr (AMODE != A_CONV3X3) {
-    const int64_t nwork = (int64_t)((p.M + BM - 1) / BM) * p.ntiles * p.splits;
-    if (g_ring == 2 || (g_ring == 1 && nwork <= g_ring_max_work)) return launch_ring<T, AMODE>(p, stream);
+    if (g_ring == 2 || (g_ring == 1 && prefer_ring(AMODE, p))) return launch_ring<T, AMODE>(p, stream);
   }
   return launch1<T, AMODE, false>(p, stream);
 }

@@ -29,7 +29,7 @@ lib.pm_debug_ring_prof.restype = None
 prof = torch.zeros(256 * 8 * 4, dtype=torch.int64, device="cuda")
 lib.pm_debug_ring_prof(prof.data_ptr())
 P = lambda t: t.data_ptr()
-for M, N, K in ((2560, 1280, 3840), (10240, 640, 2560), (40960, 320, 320), (40960, 320, 1280), (640, 1280, 5120)):
+for M, N, K in ((2560, 1280, 3840), (10240, 640, 2560), (40960, 320, 320), (40960, 960, 320), (40960, 320, 1280), (10240, 640, 640)):
     a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
     w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16) * 0.02
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
