@@ -267,6 +267,26 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, f32x4 (&acc)[
     }
     return;
   }
+  if (geglu && (nout & 3) == 0 && (ldc & 3) == 0) {
+    // fast GEGLU flavour: value block 2jj, gate block 2jj+1 (weights packed [16 value | 16 gate]); a lane owns
+    // 4 adjacent output columns per pair: straight-line bias, erf-GELU gate, product, 8-byte stores
+    const int mrow0 = m0 + wm * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mrow0 + i * 16 + fr;
+      const int64_t mrow = m < p.M ? m : 0;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int n = (n0 >> 1) + wn * 32 + jj * 16 + 4 * fq;
+        Pack4<T> ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          ov.e[r] = from_f32<T>((acc[i][2 * jj][r] + bv[2 * jj][r]) * gelu_erf_f(acc[i][2 * jj + 1][r] + bv[2 * jj + 1][r]));
+        if (m < p.M && n < nout) *reinterpret_cast<u32x2*>(Cg + mrow * ldc + n) = ov.u;
+      }
+    }
+    return;
+  }
   if (geglu) {
     // value block 2jj, gate block 2jj+1 (weights packed [16 value | 16 gate]): 4 output columns per lane
 #pragma unroll
@@ -1126,7 +1146,6 @@ template <typename T, int AMODE> static int launch_ring(const GemmParams& p, hip
 // CU) and hides the load round trip, but owns the CU alone: it pays for every epilogue with idle MFMA time and
 // quantises the grid in rounds of 1 workgroup per CU, where the 2-stage kernel runs rounds of 2.
 static bool prefer_ring(int amode, const GemmParams& p) {
-  if (p.act == PM_ACT_GEGLU) return false;  // erf-heavy epilogue: wants a co-resident workgroup to hide it
   const int64_t nwork = (int64_t)((p.M + BM - 1) / BM) * p.ntiles * p.splits;
   if (g_ring_max_work > 0 && nwork > g_ring_max_work) return false;
   const int64_t cu = num_cus();
