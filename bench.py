@@ -206,7 +206,7 @@ def main():
             "ae_decode_ms_16_frames": decode_ms,
             "sec_per_2s_video_incl_decode": None if decode_ms is None else 50.0 * elapsed / a.steps + 1e-3 * decode_ms,
             "whole_step_mfma_frac": FLOP_PER_STEP[a.res] / (elapsed / a.steps) / 1e12 / MFMA_PEAK_TFLOPS / world,
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<A_CONV3X3> (pm_conv2d_3x3)",
+            "roofline": {"bound": "mfma", "kernel": "pm_conv2d_3x3 (gemm_ring_kernel<A_CONV3X3_FAST>; gemm_kernel for the f32-operand and strided/upsampling convs)",
                          "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "launches": n, "avg_launch_ms": ms / n,
                          "share_of_step_time": (ms * 1e-3 / 2.0) / (elapsed / a.steps)},
