@@ -177,7 +177,7 @@ __device__ __forceinline__ void store_fast(const GemmParams& p, f32x4 (&acc)[4][
 }
 
 // rows m0 + wm*64 + i*16 + fr, columns n0 + wn*64 + ...; sblock = index of this wave's 64-row block in colstats
-template <typename T>
+template <typename T, bool FAST = true>
 __device__ __forceinline__ void epilogue_regs(const GemmParams& p, f32x4 (&acc)[4][4], const float (&bv)[4][4],
                                               int m0, int n0, int wm, int wn, int fr, int fq, int sblock,
                                               int split) {
@@ -198,7 +198,7 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, f32x4 (&acc)[
   const int64_t ldc = partial ? p.N : p.ldc;
   const bool want_stats = (p.colstats != nullptr) && !partial;
   // ---- fast flavours (every shape of the U-Net except N % 8 != 0, i.e. the 4-channel output conv) ----
-  if (!geglu && (nout & 7) == 0 && (ldc & 7) == 0 && (p.R == nullptr || (p.ldr & 7) == 0)) {
+  if (FAST && !geglu && (nout & 7) == 0 && (ldc & 7) == 0 && (p.R == nullptr || (p.ldr & 7) == 0)) {
     // bias and activation in place (one uniform branch per activation, not per element group)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -267,7 +267,7 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, f32x4 (&acc)[
     }
     return;
   }
-  if (geglu && (nout & 3) == 0 && (ldc & 3) == 0) {
+  if (FAST && geglu && (nout & 3) == 0 && (ldc & 3) == 0) {
     // fast GEGLU flavour: value block 2jj, gate block 2jj+1 (weights packed [16 value | 16 gate]); a lane owns
     // 4 adjacent output columns per pair: straight-line bias, erf-GELU gate, product, 8-byte stores
     const int mrow0 = m0 + wm * 64;
@@ -415,14 +415,15 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, f32x4 (&acc)[
   }
 }
 
-// 128x128 tile, 4 waves, 2 LDS stages, 2 workgroups per CU (any shape, split-K, f32 A).  Persistent: a
-// workgroup walks work items slot, slot + G, ... and issues the first K-tile of its NEXT item before the
-// epilogue of the current one, so a tile's first global-load round trip (~2 us of a ~8 us short-K tile)
-// is hidden behind the previous tile's stores.
+// 128x128 tile, 4 waves, 2 LDS stages, 2 workgroups per CU (any shape, split-K, f32 A).
 template <typename T, int AMODE, bool A32>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   typedef typename std::conditional<A32, float, T>::type TA;  // storage type of the A operand
   constexpr int ES = sizeof(TA);
+  // Persistent walk (several work items per workgroup, the next item's first K-tile issued before this
+  // item's epilogue): measured no gain over one item per workgroup, and the extra live state pushed the
+  // f32-operand instantiations past 256 VGPRs, so it is compiled out.
+  constexpr bool PERSIST = false;
   constexpr int NT = 256;                    // threads
   constexpr int WMW = 2;                     // waves along M (2 along N)
   constexpr int BMT = WMW * 64;              // tile rows
@@ -640,7 +641,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     const int m0 = mt * BMT, n0 = nt * BN;
     const int kt0 = split * p.ktps;
     const int kt1 = (kt0 + p.ktps < nk_all) ? kt0 + p.ktps : nk_all;
-    const bool has_next = (w + G < nwork);
+    const bool has_next = PERSIST && (w + G < nwork);
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -1040,7 +1041,6 @@ static int g_num_cus = 0;
 #ifdef PM_RING_PROF
 static long long* g_ring_prof = nullptr;
 #endif
-static int g_persist = 0;  // PANDORA_GEMM_PERSIST = r > 0: cap the 2-stage kernel's grid at r x 2 workgroups per CU (persistent walk with cross-tile prefetch; measured: no gain over one item per workgroup, so off)
 static int g_split_min_nk = 24;     // PANDORA_SPLITK_MIN_NK: shortest K loop (in 64-wide tiles) that is split
 
 static int choose_splits(int64_t M, int64_t N, int64_t K, int act, int* ktps) {
@@ -1058,8 +1058,6 @@ static int choose_splits(int64_t M, int64_t N, int64_t K, int act, int* ktps) {
 
 static void plan_split(GemmParams& p, void* workspace, size_t workspace_bytes) {
   static const bool init = [] {
-    const char* e = getenv("PANDORA_GEMM_PERSIST");
-    if (e) g_persist = atoi(e);
     const char* m = getenv("PANDORA_SPLITK_MIN_NK");
     if (m) g_split_min_nk = atoi(m);
     const char* r = getenv("PANDORA_GEMM_RING");
@@ -1099,8 +1097,7 @@ template <typename T, int AMODE, bool A32> static int launch1(const GemmParams& 
   GemmParams q = p;
   q.mtiles = (p.M + BM - 1) / BM;
   const int64_t nwork = (int64_t)q.mtiles * p.ntiles * p.splits;
-  const int64_t slots = 2 * (int64_t)num_cus() * g_persist;  // 2 workgroups per CU; g_persist = 0: one item each
-  const int grid = (int)((g_persist == 0 || nwork < slots) ? nwork : slots);
+  const int grid = (int)nwork;  // one work item per workgroup (see PERSIST in the kernel)
   static bool attr_set = false;  // idempotent; a benign race sets the same value twice
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, AMODE, A32>),
