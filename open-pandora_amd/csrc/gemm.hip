@@ -517,7 +517,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         a_x[j] = pix;
       }
     }
-    if (AMODE != A_DENSE) {
+    if (AMODE == A_CONV3X3_FAST) {  // channel-chunk-major walk: K-tile s = (chunk s / 9, tap s % 9), see load_tile
+      const int chunk = kt0 / 9;
+      tap_s = kt0 - chunk * 9;
+      ch_s = chunk * BK;
+    } else if (AMODE != A_DENSE) {
       tap_s = (kt0 * BK) / p.Cin;
       ch_s = kt0 * BK - tap_s * p.Cin;
       const int k_l = kt0 * BK + lc * 8;
@@ -538,8 +542,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     if (AMODE == A_DENSE) {
       ab = Ab + (int64_t)kb * ES;
     } else if (AMODE == A_CONV3X3_FAST) {
+      // The fast 3x3 mode walks K channel-chunk-major: all 9 taps of a 64-channel chunk back to back (the
+      // packed weights stay tap-major, only the order of summation changes).  The 9 taps re-read the same
+      // input rows; tap-major put a whole pass over all channels (more than an XCD's L2 holds, with 32-64
+      // tiles in flight) between two reads of a line and the fabric saw 2-2.7x the algorithmic bytes.
       dy = tap_s / 3;
       dx = tap_s - dy * 3;
+      wb = Wb + ((int64_t)tap_s * p.Cin + ch_s) * 2;
       ab = Ab + ((int64_t)((dy - 1) * p.Win + (dx - 1)) * p.lda + ch_s) * ES;
     } else if (AMODE == A_CONVT3) {
       ab = Ab + ((int64_t)(tap_s - 1) * p.P * p.lda + ch_s) * ES;
@@ -590,7 +599,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         __builtin_amdgcn_global_load_lds((glb_void*)wsrc, (lds_void*)(Bs + dst), 16, 0, 0);
       }
     }
-    if (AMODE != A_DENSE) {  // advance the (tap, channel) walk to the next K-tile
+    if (AMODE == A_CONV3X3_FAST) {  // next tap of this channel chunk, then the next chunk
+      if (++tap_s == 9) {
+        tap_s = 0;
+        ch_s += BK;
+      }
+    } else if (AMODE != A_DENSE) {  // advance the (tap, channel) walk to the next K-tile
       ch_s += BK;
       if (ch_s >= p.Cin) {
         ch_s -= p.Cin;
@@ -724,7 +738,23 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
   const int wave = tid >> 6;
   const int G = gridDim.x;
   const int nwork = p.mtiles * p.ntiles * p.splits;
-  const int slot_id = xcd_remap(blockIdx.x, G);  // round i of this workgroup: work item i * G + slot_id
+  // Work walk.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2.  When
+  // the grid is a whole number of workgroups per XCD, XCD x owns the CONTIGUOUS id range [x*per, (x+1)*per) and
+  // its G/8 workgroups sweep it in rounds of G/8 consecutive ids: tiles that run together, and the tiles of
+  // consecutive rounds, share A / W panels in that L2 (the round-major walk i*G + slot re-read the panels from
+  // the fabric: FETCH_SIZE 2.2x the algorithmic bytes on the L0 conv, profiles/r01/pmc_traffic.md).
+  const bool xcd_walk = (G & 7) == 0 && nwork > G;
+  const int per_xcd = (nwork + 7) >> 3, gx = G >> 3;
+  const int slot_id = xcd_remap(blockIdx.x, G);  // (fallback: round i -> work item i * G + slot_id)
+  auto work_id = [&](int round) -> int {  // -1: this workgroup has no work in that round (nor later)
+    if (!xcd_walk) {
+      const int w = round * G + slot_id;
+      return w < nwork ? w : -1;
+    }
+    const int xcd = blockIdx.x & 7, local = round * gx + (blockIdx.x >> 3);
+    const int w = xcd * per_xcd + local;
+    return (local < per_xcd && w < nwork) ? w : -1;
+  };
   const int nk_all = p.K / BK;
 
   // work item -> (row tile, column tile, K slice), same supertile order as gemm_kernel
@@ -753,8 +783,8 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
     int tap_s = 0, ch_s = 0;
     int l_round = 0, l_kt = 0, l_kt1 = 0;
     auto loader_begin = [&]() -> bool {
-      const int w = l_round * G + slot_id;
-      if (w >= nwork) return false;
+      const int w = work_id(l_round);
+      if (w < 0) return false;
       int mt, nt, split;
       decode(w, mt, nt, split);
       const int m0 = mt * BM, n0 = nt * BN;
@@ -787,7 +817,11 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
           a_x[j] = pix;
         }
       }
-      if (AMODE != A_DENSE) {
+      if (AMODE == A_CONV3X3_FAST) {  // channel-chunk-major walk (see gemm_kernel's load_tile)
+        const int chunk = l_kt / 9;
+        tap_s = l_kt - chunk * 9;
+        ch_s = chunk * BK;
+      } else if (AMODE != A_DENSE) {
         tap_s = (l_kt * BK) / p.Cin;
         ch_s = l_kt * BK - tap_s * p.Cin;
       }
@@ -802,6 +836,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
       } else if (AMODE == A_CONV3X3_FAST) {
         dy = tap_s / 3;
         dx = tap_s - dy * 3;
+        wb = Wb + ((int64_t)tap_s * p.Cin + ch_s) * 2;
         ab = Ab + ((int64_t)((dy - 1) * p.Win + (dx - 1)) * p.lda + ch_s) * 2;
       } else {
         ab = Ab + ((int64_t)(tap_s - 1) * p.P * p.lda + ch_s) * 2;
@@ -827,7 +862,12 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
         __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(As + dst), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((glb_void*)(wb + b_off[j]), (lds_void*)(Bs + dst), 16, 0, 0);
       }
-      if (AMODE != A_DENSE) {
+      if (AMODE == A_CONV3X3_FAST) {
+        if (++tap_s == 9) {
+          tap_s = 0;
+          ch_s += BK;
+        }
+      } else if (AMODE != A_DENSE) {
         ch_s += BK;
         if (ch_s >= p.Cin) {
           ch_s -= p.Cin;
@@ -915,9 +955,9 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
   read_frags(fa0, fb0, 0, slot0);
 
   for (int c_round = 0;; ++c_round) {
-    const int w = c_round * G + slot_id;
-    if (w >= nwork) break;
-    const bool last_tile = (w + G >= nwork);
+    const int w = work_id(c_round);
+    if (w < 0) break;
+    const bool last_tile = (work_id(c_round + 1) < 0);
     int mt, nt, split;
     decode(w, mt, nt, split);
     const int m0 = mt * BM, n0 = nt * BN;
