@@ -459,6 +459,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     const int rin = wg - grp * GM * p.ntiles;
     nt = rin / gm;
     mt = first_m + (rin - nt * gm);
+    if (AMODE == A_CONVT3) {
+      // temporal conv: row tile (frame f, pixel block b) reads the same pixel block of frames f-1, f, f+1.
+      // Enumerate the row tiles pixel-block-major (consecutive ids = consecutive frames of one block), so the
+      // three readers of an input tile run together on one XCD instead of a whole frame of tiles apart
+      const int bpf = p.P / BM;  // pixel blocks per frame (remap only when tiles do not straddle frames)
+      if (bpf * BM == p.P && p.mtiles == bpf * p.F) mt = (mt % p.F) * bpf + (mt / p.F);
+    }
   };
 
   const char* const Ab = reinterpret_cast<const char*>(p.A);
@@ -768,6 +775,13 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
     const int rin = wg - grp * GM * p.ntiles;
     nt = rin / gm;
     mt = first_m + (rin - nt * gm);
+    if (AMODE == A_CONVT3) {
+      // temporal conv: row tile (frame f, pixel block b) reads the same pixel block of frames f-1, f, f+1.
+      // Enumerate the row tiles pixel-block-major (consecutive ids = consecutive frames of one block), so the
+      // three readers of an input tile run together on one XCD instead of a whole frame of tiles apart
+      const int bpf = p.P / BM;  // pixel blocks per frame (remap only when tiles do not straddle frames)
+      if (bpf * BM == p.P && p.mtiles == bpf * p.F) mt = (mt % p.F) * bpf + (mt / p.F);
+    }
   };
 
   if (wave >= 4) {
