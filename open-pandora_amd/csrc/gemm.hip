@@ -42,6 +42,7 @@ struct GemmParams {
   const void* halo_lo;
   const void* halo_hi;
   const void* zero;
+  int64_t a_bytes;  // conv modes: bytes of the input tensor reachable from A (bound of the buffer descriptor)
 #ifdef PM_RING_PROF
   long long* prof;  // [grid][8 waves][4] cycle sums (tools/ring_prof.py)
 #endif
@@ -482,6 +483,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   const int lc = (tid & 7) ^ (lr & 7);
   uint32_t b_off[BP], a_off[4];
   int a_y[4], a_x[4];
+  uint32_t inv[4] = {0u, 0u, 0u, 0u};  // fast conv modes: per row, the taps that are zero padding (see load_tile)
   // (tap, channel) position of the K walk.  Fast modes: one tap per K-tile (Cin % 64 == 0), tracked as
   // wave-uniform scalars.  General conv (stem Cin = 8, nearest-x2 upsample): per-lane.
   int tap_s = 0, ch_s = 0;       // uniform: tap and first channel of the current K-tile
@@ -512,16 +514,25 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
         a_y[j] = oy * p.stride + 1 - p.pad;  // tap (dy, dx) reads virtual pixel (a_y + dy - 1, a_x + dx - 1)
         a_x[j] = ox * p.stride + 1 - p.pad;
-        if (AMODE == A_CONV3X3_FAST)  // no upsample: offset of the centre tap, the tap shift is uniform
+        if (AMODE == A_CONV3X3_FAST) {  // no upsample: offset of the centre tap, the tap shift is uniform
           a_off[j] = (uint32_t)((((int64_t)f * p.Hin + a_y[j]) * p.Win + a_x[j]) * p.lda * ES + lc * 8 * ES);
-        else
+          uint32_t bad = 0;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const int ty = t / 3, tx = t - ty * 3;
+            const bool ok = (unsigned)(a_y[j] + ty - 1) < (unsigned)p.Hv && (unsigned)(a_x[j] + tx - 1) < (unsigned)p.Wv;
+            bad |= ok ? 0u : (1u << t);
+          }
+          inv[j] = bad;
+        } else
           a_off[j] = (uint32_t)((int64_t)f * p.Hin * p.Win * p.lda * ES);
       } else {
         const int f = m / p.P;
         const int pix = m - f * p.P;
         a_off[j] = (uint32_t)((((int64_t)f * p.P + pix) * p.lda + lc * 8) * ES);
         a_y[j] = f;
-        a_x[j] = pix;
+        a_x[j] = (int)(uint32_t)(((int64_t)pix * p.lda + lc * 8) * ES);  // byte offset of this row inside a halo frame
+        inv[j] = (f == 0 ? 1u : 0u) | (f == p.F - 1 ? 4u : 0u);  // taps reaching frame -1 / frame F
       }
     }
     if (AMODE == A_CONV3X3_FAST) {  // channel-chunk-major walk: K-tile s = (chunk s / 9, tap s % 9), see load_tile
@@ -545,6 +556,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     const bool kin_l = kb + lc * 8 < p.K;  // only the general conv mode can have a K tail
     const char* wb = Wb + (int64_t)kb * 2;
     const char* ab = Ab;
+    const char *hlo = nullptr, *hhi = nullptr;  // temporal mode: halo frames at this K-tile's channel (uniform)
     int dy = 0, dx = 0;
     if (AMODE == A_DENSE) {
       ab = Ab + (int64_t)kb * ES;
@@ -559,12 +571,31 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
       ab = Ab + ((int64_t)((dy - 1) * p.Win + (dx - 1)) * p.lda + ch_s) * ES;
     } else if (AMODE == A_CONVT3) {
       ab = Ab + ((int64_t)(tap_s - 1) * p.P * p.lda + ch_s) * ES;
+      hlo = p.halo_lo ? reinterpret_cast<const char*>(p.halo_lo) + (int64_t)ch_s * ES : nullptr;
+      hhi = p.halo_hi ? reinterpret_cast<const char*>(p.halo_hi) + (int64_t)ch_s * ES : nullptr;
     } else {
       dy = tap_l / 3;
       dx = tap_l - dy * 3;
     }
+    // Fast conv modes without halo frames, 16-bit operands: the A tile goes through a buffer descriptor whose
+    // base carries the uniform tap shift; a padding lane gets offset ~0 = out of range, for which
+    // `buffer_load ... lds` writes zeros (see gemm_ring_kernel): 2-3 VALU per DMA instead of ~8.
+    const bool use_desc = !A32 && (AMODE == A_CONV3X3_FAST || AMODE == A_CONVT3) && p.halo_lo == nullptr && p.halo_hi == nullptr;
+    if constexpr (!A32) {
+      if (use_desc) {
+        const uint32_t nrec = (uint32_t)((Ab + p.a_bytes) - ab);
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ab, (short)0, (int)nrec, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t voff = a_off[j] | (uint32_t)(-(int)((inv[j] >> tap_s) & 1u));
+          const int dst = buf * STAGE_BYTES + (RSTEP * j + 8 * wave) * 128;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(As + dst), 16, voff, 0, 0, 0);
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      if (use_desc) break;
       const char* src;
       if (AMODE == A_DENSE) {
         src = ab + a_off[j];
@@ -572,13 +603,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         const bool ok = (unsigned)(a_y[j] + dy - 1) < (unsigned)p.Hv && (unsigned)(a_x[j] + dx - 1) < (unsigned)p.Wv;
         src = ok ? ab + a_off[j] : zero;
       } else if (AMODE == A_CONVT3) {
+        // (per-row halo offsets are precomputed: the 64-bit multiplies that stood here made the loader the
+        // bottleneck of the temporal conv: 1 250-1 450 issue cycles per K-step against 550 for dense)
         const int sf = a_y[j] + tap_s - 1;
-        if (sf < 0)
-          src = p.halo_lo ? reinterpret_cast<const char*>(p.halo_lo) + ((int64_t)a_x[j] * p.lda + ch_s + lc * 8) * ES : zero;
-        else if (sf >= p.F)
-          src = p.halo_hi ? reinterpret_cast<const char*>(p.halo_hi) + ((int64_t)a_x[j] * p.lda + ch_s + lc * 8) * ES : zero;
-        else
-          src = ab + a_off[j];
+        src = ab + a_off[j];
+        if (sf < 0) src = hlo ? hlo + (uint32_t)a_x[j] : zero;
+        if (sf >= p.F) src = hhi ? hhi + (uint32_t)a_x[j] : zero;
       } else {
         int iy = a_y[j] + dy - 1, ix = a_x[j] + dx - 1;
         const bool ok = kin_l && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv;
@@ -786,7 +816,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
 
   if (wave >= 4) {
     // ================= loader waves (see gemm_kernel for the source-side swizzle / scalarised K walk) =====
-    const int lw = wave - 4;
+    const int lw = __builtin_amdgcn_readfirstlane(wave - 4);  // (scalar: the DMA's LDS base goes to M0 by SALU)
     const int r8 = lane >> 3;             // row inside an 8-row DMA piece; tile row = 32*j + 8*lw + r8
     const int lc = (lane & 7) ^ r8;       // logical 16-byte k-chunk this lane fetches ((row & 7) == r8)
     const char* const Ab = reinterpret_cast<const char*>(p.A);
@@ -794,6 +824,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
     const char* const zero = reinterpret_cast<const char*>(p.zero);
     uint32_t b_off[4], a_off[4];
     int a_y[4], a_x[4];
+    uint32_t inv[4] = {0u, 0u, 0u, 0u};  // conv modes: per row, the taps that are zero padding
     int tap_s = 0, ch_s = 0;
     int l_round = 0, l_kt = 0, l_kt1 = 0;
     auto loader_begin = [&]() -> bool {
@@ -823,12 +854,21 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
           a_y[j] = oy * p.stride + 1 - p.pad;
           a_x[j] = ox * p.stride + 1 - p.pad;
           a_off[j] = (uint32_t)((((int64_t)f * p.Hin + a_y[j]) * p.Win + a_x[j]) * p.lda * 2 + lc * 16);
+          uint32_t bad = 0;  // bit t: tap t of this row is zero padding
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const int ty = t / 3, tx = t - ty * 3;
+            const bool ok = (unsigned)(a_y[j] + ty - 1) < (unsigned)p.Hv && (unsigned)(a_x[j] + tx - 1) < (unsigned)p.Wv;
+            bad |= ok ? 0u : (1u << t);
+          }
+          inv[j] = bad;
         } else {
           const int f = m / p.P;
           const int pix = m - f * p.P;
           a_off[j] = (uint32_t)((((int64_t)f * p.P + pix) * p.lda + lc * 8) * 2);
           a_y[j] = f;
-          a_x[j] = pix;
+          a_x[j] = (int)(uint32_t)(((int64_t)pix * p.lda + lc * 8) * 2);  // byte offset inside a halo frame
+          inv[j] = (f == 0 ? 1u : 0u) | (f == p.F - 1 ? 4u : 0u);  // taps reaching frame -1 / frame F
         }
       }
       if (AMODE == A_CONV3X3_FAST) {  // channel-chunk-major walk (see gemm_kernel's load_tile)
@@ -844,6 +884,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
     auto load_tile = [&](int kt, int buf) {
       const char* wb = Wb + (int64_t)kt * (BK * 2);
       const char* ab = Ab;
+      const char *hlo = nullptr, *hhi = nullptr;
       int dy = 0, dx = 0;
       if (AMODE == A_DENSE) {
         ab = Ab + (int64_t)kt * (BK * 2);
@@ -854,27 +895,47 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
         ab = Ab + ((int64_t)((dy - 1) * p.Win + (dx - 1)) * p.lda + ch_s) * 2;
       } else {
         ab = Ab + ((int64_t)(tap_s - 1) * p.P * p.lda + ch_s) * 2;
+        hlo = p.halo_lo ? reinterpret_cast<const char*>(p.halo_lo) + (int64_t)ch_s * 2 : nullptr;
+        hhi = p.halo_hi ? reinterpret_cast<const char*>(p.halo_hi) + (int64_t)ch_s * 2 : nullptr;
       }
+      // Conv modes without halo frames: the A tile goes through a buffer descriptor whose base carries the
+      // (uniform) tap shift and channel offset; a lane's offset is its constant centre-tap offset, and a
+      // padding lane gets offset ~0: out of range, for which `buffer_load ... lds` writes ZEROS into LDS
+      // (tools/probes/buffer_lds_oob.hip).  2 VALU per DMA instead of the ~8 of a per-lane 64-bit pointer
+      // select against a zero page (in-kernel stamps: loader issue 950 -> 560 cycles per K-step, which
+      // had made the LOADER the bottleneck of the convs).
+      const bool use_desc = (AMODE != A_DENSE) && p.halo_lo == nullptr && p.halo_hi == nullptr;
+      if (use_desc) {
+        const uint32_t nrec = (uint32_t)((Ab + p.a_bytes) - ab);
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ab, (short)0, (int)nrec, 0x00020000);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const char* src;
-        if (AMODE == A_DENSE) {
-          src = ab + a_off[j];
-        } else if (AMODE == A_CONV3X3_FAST) {
-          const bool ok = (unsigned)(a_y[j] + dy - 1) < (unsigned)p.Hv && (unsigned)(a_x[j] + dx - 1) < (unsigned)p.Wv;
-          src = ok ? ab + a_off[j] : zero;
-        } else {
-          const int sf = a_y[j] + tap_s - 1;
-          if (sf < 0)
-            src = p.halo_lo ? reinterpret_cast<const char*>(p.halo_lo) + ((int64_t)a_x[j] * p.lda + ch_s + lc * 8) * 2 : zero;
-          else if (sf >= p.F)
-            src = p.halo_hi ? reinterpret_cast<const char*>(p.halo_hi) + ((int64_t)a_x[j] * p.lda + ch_s + lc * 8) * 2 : zero;
-          else
-            src = ab + a_off[j];
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t voff = a_off[j] | (uint32_t)(-(int)((inv[j] >> tap_s) & 1u));
+          const int dst = buf * STAGE_BYTES + (32 * j + 8 * lw) * 128;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(As + dst), 16, voff, 0, 0, 0);
+          __builtin_amdgcn_global_load_lds((glb_void*)(wb + b_off[j]), (lds_void*)(Bs + dst), 16, 0, 0);
         }
-        const int dst = buf * STAGE_BYTES + (32 * j + 8 * lw) * 128;
-        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(As + dst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void*)(wb + b_off[j]), (lds_void*)(Bs + dst), 16, 0, 0);
+      } else {
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const char* src;
+          if (AMODE == A_DENSE) {
+            src = ab + a_off[j];
+          } else if (AMODE == A_CONV3X3_FAST) {
+            const bool ok = (unsigned)(a_y[j] + dy - 1) < (unsigned)p.Hv && (unsigned)(a_x[j] + dx - 1) < (unsigned)p.Wv;
+            src = ok ? ab + a_off[j] : zero;
+          } else {
+            // (per-row halo offsets are precomputed: the 64-bit multiplies that stood here made the loader the
+            // bottleneck of the temporal conv: 1 250-1 450 issue cycles per K-step against 550 for dense)
+            const int sf = a_y[j] + tap_s - 1;
+            src = ab + a_off[j];
+            if (sf < 0) src = hlo ? hlo + (uint32_t)a_x[j] : zero;
+            if (sf >= p.F) src = hhi ? hhi + (uint32_t)a_x[j] : zero;
+          }
+          const int dst = buf * STAGE_BYTES + (32 * j + 8 * lw) * 128;
+          __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(As + dst), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((glb_void*)(wb + b_off[j]), (lds_void*)(Bs + dst), 16, 0, 0);
+        }
       }
       if (AMODE == A_CONV3X3_FAST) {
         if (++tap_s == 9) {
@@ -1218,7 +1279,7 @@ template <typename T, int AMODE> static int launch(const GemmParams& p, int flag
 
 // the loaders address an operand as (64-bit uniform base) + (32-bit lane byte offset)
 static bool fits_u32(int64_t elements, int flags) {
-  return elements * ((flags & PM_FLAG_A_F32) ? 4 : 2) < (1ll << 32);
+  return elements * ((flags & PM_FLAG_A_F32) ? 4 : 2) < (1ll << 32) - (1ll << 24);  // (margin: a conv's descriptor base sits up to a tap shift before A)
 }
 
 static int check_common(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K,
@@ -1286,6 +1347,7 @@ extern "C" int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const f
   p.Hin = (int)H; p.Win = (int)W; p.Hv = (int)Hv; p.Wv = (int)Wv; p.Cin = (int)Cin;
   p.Ho = (int)Ho; p.Wo = (int)Wo; p.stride = stride; p.ups = upsample2x ? 1 : 0; p.pad = pad_lo;
   p.zero = zero_page;
+  p.a_bytes = ((F * H * W - 1) * ldx + Cin) * ((flags & PM_FLAG_A_F32) ? 4 : 2);
   plan_split(p, workspace, workspace_bytes);
   if (!upsample2x && (Cin % BK) == 0)
     PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_CONV3X3_FAST>(p, flags, (hipStream_t)stream)));
@@ -1314,6 +1376,7 @@ extern "C" int pm_conv_temporal_k3(const void* x, int64_t ldx, const void* halo_
   p.ntiles = (int)((Cout + BN - 1) / BN);
   p.Cin = (int)Cin; p.F = (int)F; p.P = (int)P; p.halo_lo = halo_lo; p.halo_hi = halo_hi;
   p.zero = zero_page;
+  p.a_bytes = ((F * P - 1) * ldx + Cin) * ((flags & PM_FLAG_A_F32) ? 4 : 2);
   plan_split(p, workspace, workspace_bytes);
   PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_CONVT3>(p, flags, (hipStream_t)stream)));
 }

@@ -29,6 +29,51 @@ lib.pm_debug_ring_prof.restype = None
 prof = torch.zeros(256 * 8 * 4, dtype=torch.int64, device="cuda")
 lib.pm_debug_ring_prof(prof.data_ptr())
 P = lambda t: t.data_ptr()
+def report(tag, us):
+    d = prof.view(256, 8, 4).double().cpu()
+    nb = int((d[:, 0, 3] > 0).sum())
+    cons, load = d[:nb, :4], d[:nb, 4:]
+    print(f"{tag}: {us:.1f} us, {nb} blocks, {cons[:, :, 3].mean():.1f} K-steps/block  (clock64 ticks per K-step, mean over waves)")
+    print(f"   consumer: barrier {cons[:, :, 0].sum() / cons[:, :, 3].sum():7.0f}  compute {cons[:, :, 1].sum() / cons[:, :, 3].sum():7.0f}"
+          f"  epilogue/tile-steps {cons[:, :, 2].sum() / cons[:, :, 3].sum():7.0f}  total/blk {(cons[:, :, :3].sum(2)).mean():9.0f}")
+    print(f"   loader  : vmwait  {load[:, :, 0].sum() / load[:, :, 3].sum():7.0f}  barrier {load[:, :, 1].sum() / load[:, :, 3].sum():7.0f}"
+          f"  issue {load[:, :, 2].sum() / load[:, :, 3].sum():7.0f}  total/blk {(load[:, :, :3].sum(2)).mean():9.0f}")
+
+
+# temporal conv, unsplit (as the fused-statistics calls run it)
+for F, Pp, C in ((16, 160, 1280), (16, 2560, 320)):
+    x = torch.randn(F * Pp, C, device="cuda", dtype=torch.bfloat16)
+    wt = torch.randn(C, 3 * C, device="cuda", dtype=torch.bfloat16) * 0.02
+    out = torch.empty(F * Pp, C, device="cuda", dtype=torch.float32)
+    for it in range(3):
+        prof.zero_()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = lib.pm_conv_temporal_k3(P(x), C, None, None, P(wt), None, None, 0, P(out), C, F, Pp, C, C, P(ops.zero_page),
+                                     2, ops.dt, None, 0, None, torch.cuda.current_stream().cuda_stream)
+        e1.record()
+        torch.cuda.synchronize()
+        assert rc == 0, rc
+    report(f"conv_t3 F={F} P={Pp} C={C}", e0.elapsed_time(e1) * 1e3)
+
+# 3x3 conv (fast mode)
+for F, H, W, C in ((16, 40, 64, 320), (16, 20, 32, 640)):
+    x = torch.randn(F * H * W, C, device="cuda", dtype=torch.bfloat16)
+    wp = torch.randn(C, 9 * C, device="cuda", dtype=torch.bfloat16) * 0.02
+    out = torch.empty(F * H * W, C, device="cuda", dtype=torch.float32)
+    for it in range(3):
+        prof.zero_()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = lib.pm_conv2d_3x3(P(x), C, P(wp), None, None, 0, P(out), C, F, H, W, C, C, 1, 0, 1, P(ops.zero_page), 2, ops.dt,
+                               None, 0, None, torch.cuda.current_stream().cuda_stream)
+        e1.record()
+        torch.cuda.synchronize()
+        assert rc == 0, rc
+    report(f"conv3x3 F={F} {H}x{W} C={C}", e0.elapsed_time(e1) * 1e3)
+
 for M, N, K in ((2560, 1280, 3840), (10240, 640, 2560), (40960, 320, 320), (40960, 960, 320), (40960, 320, 1280), (10240, 640, 640)):
     a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
     w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16) * 0.02
