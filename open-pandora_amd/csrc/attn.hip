@@ -110,9 +110,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 
   for (int seg = 0; seg < (SEG2 ? p.nseg : 1); ++seg) {
     const int Nk = p.Nk[seg];
-    const T* kg = reinterpret_cast<const T*>(p.k[seg]) + (int64_t)b * p.k_bs[seg] + head * 64 + lc * 8;
-    const T* vg = reinterpret_cast<const T*>(p.v[seg]) + (int64_t)b * p.k_bs[seg] + head * 64 + lc * 8;
-    const int64_t krs = p.k_rs[seg];
+    // wave-uniform bases (this block's batch element and head); lanes add 32-bit byte offsets, so the DMAs use
+    // the "scalar base + 32-bit lane offset" address form (a per-lane 64-bit address costs the DMA about twice
+    // the issue time: measured on the GEMM loaders, profiles/r01/ring_gemm_inkernel_stamps.txt)
+    const char* const kbase = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.k[seg]) + (int64_t)b * p.k_bs[seg] + head * 64);
+    const char* const vbase = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.v[seg]) + (int64_t)b * p.k_bs[seg] + head * 64);
+    const uint32_t krs2 = (uint32_t)(p.k_rs[seg] * 2);  // row stride in bytes (Nk * row bytes < 4 GiB: checked by the launcher)
     const int nkt = (Nk + KV_TILE - 1) / KV_TILE;
 
     // K/V tiles go global -> LDS by DMA (1 KiB per wave-instruction, lane-linear image); the XOR
@@ -121,16 +124,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     // 32-row MFMA operand) resp.  slot ^ (((row >> 1) & 1) << 2)  (V: conflict-free transposed reads).
     const int kc = (tid & 7) ^ ((lr >> 1) & 7);
     const int vc = (tid & 7) ^ (((lr >> 1) & 1) << 2);
-    const T* kgl = kg + (kc - lc) * 8;
-    const T* vgl = vg + (vc - lc) * 8;
     auto load_kv = [&](int kt, int buf) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         int key = kt * KV_TILE + lr + 32 * j;
         if (key > Nk - 1) key = Nk - 1;
         const int dst = buf * KV_TILE_BYTES + (32 * j + 8 * wave) * 128;
-        __builtin_amdgcn_global_load_lds((glb_void*)(kgl + (int64_t)key * krs), (lds_void*)(Ks + dst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void*)(vgl + (int64_t)key * krs), (lds_void*)(Vs + dst), 16, 0, 0);
+        const uint32_t row = (uint32_t)key * krs2;
+        __builtin_amdgcn_global_load_lds((glb_void*)(kbase + (row + (uint32_t)kc * 16)), (lds_void*)(Ks + dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void*)(vbase + (row + (uint32_t)vc * 16)), (lds_void*)(Vs + dst), 16, 0, 0);
       }
     };
 
@@ -400,6 +402,7 @@ extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const voi
   if (B < 1 || heads < 1 || Nq < 1 || Nk1 < 1 || (k2 && Nk2 < 1)) return PM_E_SHAPE;
   if ((q_bs | q_rs | k1_bs | k1_rs | o_bs | o_rs) & 7) return PM_E_SHAPE;
   if (k2 && ((k2_bs | k2_rs) & 7)) return PM_E_SHAPE;
+  if (Nk1 * k1_rs * 2 >= (1ll << 32) || (k2 && Nk2 * k2_rs * 2 >= (1ll << 32))) return PM_E_SHAPE;  // 32-bit lane byte offsets
   if (B * heads * ((Nq + 127) / 128) > (1ll << 30)) return PM_E_SHAPE;
   AttnParams p{};
   p.q = q; p.o = o; p.q_bs = q_bs; p.q_rs = q_rs; p.o_bs = o_bs; p.o_rs = o_rs;
