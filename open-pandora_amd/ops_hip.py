@@ -31,6 +31,8 @@ class HipOps:
         if self.device.type != "cuda":
             raise capi.PandoraKernelError("HipOps needs a ROCm device (cuda:N)")
         self.zero_page = torch.zeros(256, dtype=torch.uint8, device=self.device)
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
         # split-K scratch for the GEMM family (deep levels: few output tiles, long K); one buffer per
         # op table is enough because every launch on the stream is ordered after the previous reduce
         self.ws_bytes = int(workspace_mb) << 20
@@ -38,6 +40,10 @@ class HipOps:
 
     # -- helpers ---------------------------------------------------------------------------------
     def _stream(self):
+        # raw handle of torch's current stream on this device; the C getter avoids building a Stream object
+        # per launch (a quarter of the host-side cost of an eagerly launched forward, tools/host_profile.py)
+        if self._raw_stream is not None:
+            return self._raw_stream(self._dev_index)
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def _rows(self, t, f32_ok=False):
