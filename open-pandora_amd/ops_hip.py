@@ -80,7 +80,7 @@ class HipOps:
     def _stats_begin(self, M, n_out, stats, K=0):
         if stats is None:
             return None
-        NI, groups = stats
+        NI, groups = stats[0], stats[1]
         if M % NI or (M // NI) % 64 or n_out % groups:
             return None
         if self.ws_bytes and self.lib.pm_gemm_workspace_bytes(M, n_out, K, 0) > 0:
@@ -90,9 +90,10 @@ class HipOps:
     def _stats_end(self, out, col, stats):
         if stats is None:
             return out
-        NI, groups = stats
+        NI, groups = stats[0], stats[1]
         if col is None:
-            return out, self.groupnorm_stats(out, NI, groups)
+            # (NI, groups, "lazy"): the caller only wants statistics that come for free from the epilogue
+            return (out, None) if len(stats) > 2 else (out, self.groupnorm_stats(out, NI, groups))
         M, n_out = out.shape
         tot = torch.empty(NI, groups, 2, dtype=torch.float32, device=self.device)
         rc = self.lib.pm_groupnorm_finalize_colstats(_ptr(col), _ptr(tot), M // 64, n_out, NI, groups, self._stream())

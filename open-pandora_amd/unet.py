@@ -178,7 +178,7 @@ class TimestepEmbedSequential(nn.Sequential):
 # ------------------------------------------------------------------------------------------------
 class _Ctx:
     """Per-forward execution state."""
-    __slots__ = ("ops", "fp", "F", "H", "W", "emb_bias", "ctx_text", "ctx_img", "w")
+    __slots__ = ("ops", "fp", "F", "H", "W", "emb_bias", "ctx_text", "ctx_img", "w", "stats")
 
 
 class UNetModel(nn.Module):
@@ -357,10 +357,32 @@ class UNetModel(nn.Module):
     def _gn(self, c, x, gb, eps, silu, per_frame, totals=None):
         """`totals`: {sum, sumsq} already produced by the epilogue of the op that wrote x."""
         ops = c.ops
+        if totals is None:  # statistics a previous module's last op left behind for this very tensor
+            hit = c.stats.pop(x.data_ptr(), None)
+            if hit is not None and hit[1] == tuple(x.shape):
+                tot = hit[0]
+                need = c.F if per_frame else 1
+                if tot.shape[0] == need:
+                    totals = tot
+                elif need == 1:
+                    totals = tot.sum(0, keepdim=True)  # per-frame sums add up to the (T,H,W) sums
         if per_frame:
             return ops.groupnorm(x, gb[0], gb[1], eps, c.F, silu, totals=totals)
         red = c.fp.reduce_stats if c.fp is not None else None
         return ops.groupnorm(x, gb[0], gb[1], eps, 1, silu, stats_reduce=red, totals=totals)
+
+    def _stream_stats(self, c):
+        """Statistics request for an op that writes the residual stream: per frame when a frame is a whole
+        number of 64-row blocks (the (T,H,W) sums follow by addition), else over the clip; "lazy" = only if the
+        epilogue can emit them (no separate statistics pass is added on their account)."""
+        return (c.F if (c.H * c.W) % 64 == 0 else 1, 32, "lazy")
+
+    @staticmethod
+    def _keep_stats(c, out_tot):
+        out, tot = out_tot
+        if tot is not None:
+            c.stats[out.data_ptr()] = (tot, tuple(out.shape))
+        return out
 
     def _res_block(self, c, mod, x):
         ops, e = c.ops, c.w[self._names[mod]]
@@ -373,7 +395,8 @@ class UNetModel(nn.Module):
         h = self._gn(c, h, e["gn2"], 1e-5, True, True, totals=tot)
         skip = x if e["skip"] is None else ops.gemm(x, e["skip"][0], e["skip"][1], stream=True)
         if not mod.use_temporal_conv:
-            return ops.conv3x3(h, e["conv2"][0], e["conv2"][1], c.F, c.H, c.W, residual=skip, stream=True)
+            return self._keep_stats(c, ops.conv3x3(h, e["conv2"][0], e["conv2"][1], c.F, c.H, c.W, residual=skip,
+                                                   stream=True, stats=self._stream_stats(c)))
         h, tot = ops.conv3x3(h, e["conv2"][0], e["conv2"][1], c.F, c.H, c.W, residual=skip, stream=True,
                              stats=(1, 32))
         ident = h
@@ -385,7 +408,8 @@ class UNetModel(nn.Module):
             if i < 3:
                 h, tot = ops.conv_t3(t, wp, b, c.F, P, halo_lo=lo_h, halo_hi=hi_h, stream=True, stats=(1, 32))
             else:
-                h = ops.conv_t3(t, wp, b, c.F, P, residual=ident, halo_lo=lo_h, halo_hi=hi_h, stream=True)
+                h = self._keep_stats(c, ops.conv_t3(t, wp, b, c.F, P, residual=ident, halo_lo=lo_h, halo_hi=hi_h,
+                                                    stream=True, stats=self._stream_stats(c)))
         return h
 
     def _block(self, c, e, h, mod, temporal, F, P, gather=False):
@@ -433,10 +457,14 @@ class UNetModel(nn.Module):
         h = self._block(c, e, h, mod, temporal, F, P, gather)
         if sharded:
             h = c.fp.pixels_to_frames(h, c.H * c.W)
-        return ops.gemm(h, *e["proj_out"], residual=x, stream=True)
+        return self._keep_stats(c, ops.gemm(h, *e["proj_out"], residual=x, stream=True, stats=self._stream_stats(c)))
 
     def _run(self, c, seq, h):
         for layer in seq:
+            # the only statistics worth keeping are those of this layer's (live) input: an entry of a tensor
+            # that has been freed meanwhile could otherwise meet a new tensor at the same address
+            if c.stats:
+                c.stats = {k: v for k, v in c.stats.items() if k == h.data_ptr()}
             if isinstance(layer, ResBlock):
                 h = self._res_block(c, layer, h)
             elif isinstance(layer, SpatialTransformer):
@@ -484,6 +512,7 @@ class UNetModel(nn.Module):
         assert b == 1, "the reference path runs batch size 1 (model.py:794)"
         c = _Ctx()
         c.ops, c.fp, c.w = self.ops, self.fp, self._packed
+        c.stats = {}  # data_ptr -> (GroupNorm totals, shape) left behind by the op that wrote that stream tensor
         c.F, c.H, c.W = t, hh, ww
         ops = c.ops
         T_total = t if c.fp is None else c.fp.total_frames

@@ -37,7 +37,7 @@ class TorchOps:
     def _with_stats(y, stats):
         if stats is None:
             return y
-        NI, groups = stats
+        NI, groups = stats[0], stats[1]  # (a third element, "lazy", is a HipOps hint)
         yg = y.float().reshape(NI, y.shape[0] // NI, groups, -1)
         return y, torch.stack([yg.sum((1, 3)), (yg * yg).sum((1, 3))], -1)
 
