@@ -71,9 +71,9 @@ int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float*
 
 /* Fused GroupNorm statistics.  When `colstats` is not NULL the GEMM-family epilogue also writes, per
  * block of 64 output rows and output column, {sum, sum of squares} of exactly the values it stores:
- * colstats [ceil(M/64)][Nout][2] f32 (the call then runs unsplit).  pm_groupnorm_finalize_colstats turns
+ * colstats [ceil(M/rows)][Nout][2] f32, rows = pm_gemm_colstats_rows(...) (64, or 16 for a split-K call).  pm_groupnorm_finalize_colstats turns
  * them into GroupNorm totals [NI][groups][2] for NI instances of mtiles/NI consecutive row blocks each
- * (mtiles = ceil(M/64); per-frame statistics: rows per frame % 64 == 0; (T,H,W): NI = 1), replacing pm_groupnorm_stats' read
+ * (mtiles = ceil(M/rows); per-frame statistics: rows per frame % rows == 0; (T,H,W): NI = 1), replacing pm_groupnorm_stats' read
  * pass over the tensor for the GroupNorm that follows a conv (openaimodel3d.py:178-183,258-269). */
 int pm_groupnorm_finalize_colstats(const float* colstats, float* totals, int64_t mtiles, int64_t C,
                                    int64_t NI, int groups, void* stream);
@@ -85,6 +85,12 @@ int pm_groupnorm_finalize_colstats(const float* colstats, float* totals, int64_t
  * too small workspace is legal everywhere and simply disables splitting.  For the conv entry points
  * M = F*Ho*Wo, N = Cout, K = 9*Cin (3*Cin for the temporal conv). */
 size_t pm_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int act);
+
+/* Row-block size of the fused GroupNorm column sums (`colstats`) for a call shape: 64 when the call runs
+ * unsplit (sums come from the main kernel's epilogue), 16 when it splits over K with the given workspace (sums
+ * come from the reduce pass; needs N % 4 == 0, ldc % 4 == 0).  colstats is [ceil(M/rows)][Nout][2], and
+ * pm_groupnorm_finalize_colstats takes mtiles = ceil(M/rows). */
+int pm_gemm_colstats_rows(int64_t M, int64_t N, int64_t K, int act, size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------------------------------
  * pm_conv2d_3x3: implicit-GEMM 3x3 convolution, padding 1, on channels-last frames.

@@ -23,6 +23,7 @@ SIGNATURES = {
                         c_void_p, c_void_p]),
     "pm_groupnorm_finalize_colstats": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "pm_gemm_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
+    "pm_gemm_colstats_rows": (c_int, [c_int64, c_int64, c_int64, c_int, c_size_t]),
     "pm_conv2d_3x3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                               c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int,
                               c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),

@@ -1150,6 +1150,96 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
   }
 }
 
+// split-K second pass that also emits the fused GroupNorm column sums: grid (ceil(M/16), ceil(N/256)); the 256
+// threads of a block are 64 column quads x 4 row lanes: a thread owns 4 consecutive columns of rows rl, rl+4,
+// rl+8, rl+12 of a 16-row block (all its slab loads are independent and issued up front), sums the slabs in
+// slab order, applies the epilogue, stores, and accumulates {sum, sum of squares} of exactly the values stored;
+// the 4 row lanes are combined through LDS in lane order -> colstats [ceil(M/16)][N][2] (deterministic).
+// (N % 4 == 0; the deep levels whose output has too few tiles to run unsplit are exactly the ones whose
+// GroupNorms would otherwise need a separate statistics pass + finalize: 60 of the 166 per forward.)
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const GemmParams p) {
+  __shared__ float red[4][64][8];
+  const int cq4 = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int n = (blockIdx.y * 64 + cq4) * 4;
+  const int r0 = blockIdx.x * 16;
+  const int64_t slab = (int64_t)p.M * p.N;
+  const bool ncol = n < p.N;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ncol) {
+    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+    f32x4 v[4];
+    bool live[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = r0 + rl + 4 * u;
+      live[u] = m < p.M;
+      v[u] = *reinterpret_cast<const f32x4*>(p.ws + (int64_t)(live[u] ? m : 0) * p.N + n);
+    }
+    for (int sidx = 1; sidx < p.splits; ++sidx) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int m = r0 + rl + 4 * u;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p.ws + sidx * slab + (int64_t)(live[u] ? m : 0) * p.N + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[u][e] += t[e];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!live[u]) continue;
+      const int m = r0 + rl + 4 * u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = v[u][e] + bias4[e];
+        if (p.act == PM_ACT_SILU) x = silu_f(x);
+        if (p.act == PM_ACT_GELU) x = gelu_erf_f(x);
+        v[u][e] = x;
+      }
+      if (p.R) {
+        if (p.res32) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + (int64_t)m * p.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[u][e] += rr[e];
+        } else {
+          Pack4<T> rr;
+          rr.u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(p.R) + (int64_t)m * p.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[u][e] += to_f32(rr.e[e]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        cs[e] += v[u][e];
+        cq[e] = fmaf(v[u][e], v[u][e], cq[e]);
+      }
+      if (p.out32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = v[u];
+      } else {
+        Pack4<T> ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov.e[e] = from_f32<T>(v[u][e]);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + n) = ov.u;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[rl][cq4][2 * e] = cs[e];
+    red[rl][cq4][2 * e + 1] = cq[e];
+  }
+  __syncthreads();
+  if (rl == 0 && ncol && p.colstats != nullptr) {
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = ((red[0][cq4][e] + red[1][cq4][e]) + red[2][cq4][e]) + red[3][cq4][e];
+    float* dst = p.colstats + ((int64_t)blockIdx.x * p.N + n) * 2;
+    *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
+  }
+}
+
 static int g_ring = 1;  // PANDORA_GEMM_RING: 0 = never, 1 = by prefer_ring(), 2 = always
 static int g_ring_max_work = 0;  // PANDORA_GEMM_RING_MAX_WORK > 0: never use the ring kernel above that many work items
 static int g_num_cus = 0;
@@ -1184,7 +1274,9 @@ static void plan_split(GemmParams& p, void* workspace, size_t workspace_bytes) {
   (void)init;
   int ktps;
   int s = choose_splits(p.M, p.N, p.K, p.act, &ktps);
-  if (p.colstats != nullptr) {  // fused statistics live in the main kernel's epilogue
+  // fused statistics: from the main kernel's epilogue when the call runs unsplit (64-row blocks), from the
+  // reduce pass when it splits (16-row blocks, pm_gemm_colstats_rows); the reduce variant needs 4-column vectors
+  if (p.colstats != nullptr && s > 1 && ((p.N & 3) || p.act == PM_ACT_GEGLU)) {  // (pm_gemm_colstats_rows says 64 too)
     s = 1;
     ktps = (p.K + BK - 1) / BK;
   }
@@ -1195,6 +1287,19 @@ static void plan_split(GemmParams& p, void* workspace, size_t workspace_bytes) {
   p.splits = s;
   p.ktps = ktps;
   p.ws = reinterpret_cast<float*>(workspace);
+}
+
+template <typename T> static void launch_reduce(const GemmParams& p, hipStream_t stream) {
+  // (the 16-row x 256-column block mapping is also the faster plain reduce whenever 4-column vectors apply)
+  if (p.colstats != nullptr || ((p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.R == nullptr || (p.ldr & 3) == 0))) {
+    dim3 grid((unsigned)((p.M + 15) / 16), (unsigned)((p.N + 255) / 256));
+    hipLaunchKernelGGL((splitk_reduce_stats_kernel<T>), grid, dim3(256), 0, stream, p);
+    return;
+  }
+  const int64_t work = (int64_t)p.M * ((p.N + 3) / 4);
+  int64_t nb = (work + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)nb), dim3(256), 0, stream, p);
 }
 
 static int num_cus() {
@@ -1220,12 +1325,7 @@ template <typename T, int AMODE, bool A32> static int launch1(const GemmParams& 
     attr_set = true;
   }
   hipLaunchKernelGGL((gemm_kernel<T, AMODE, A32>), dim3(grid), dim3(256), lds, stream, q);
-  if (p.splits > 1) {
-    const int64_t work = (int64_t)p.M * ((p.N + 3) / 4);
-    int64_t nb = (work + 255) / 256;
-    if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)nb), dim3(256), 0, stream, p);
-  }
+  if (p.splits > 1) launch_reduce<T>(p, stream);
   return check_launch();
 }
 
@@ -1244,12 +1344,7 @@ template <typename T, int AMODE> static int launch_ring(const GemmParams& p, hip
     attr_set = true;
   }
   hipLaunchKernelGGL((gemm_ring_kernel<T, AMODE>), dim3(grid), dim3(512), RING_LDS, stream, q);
-  if (p.splits > 1) {
-    const int64_t work = (int64_t)p.M * ((p.N + 3) / 4);
-    int64_t nb = (work + 255) / 256;
-    if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)nb), dim3(256), 0, stream, p);
-  }
+  if (p.splits > 1) launch_reduce<T>(p, stream);
   return check_launch();
 }
 
@@ -1318,6 +1413,7 @@ extern "C" int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, c
   // bytes would poison the accumulator, so require a real zero source only when a tail exists.
   if (K % BK) return PM_E_SHAPE;  // all Linear layers on the path have K % 64 == 0
   plan_split(p, workspace, workspace_bytes);
+  if (p.colstats != nullptr && p.splits > 1 && ((p.ldc & 3) || (p.R != nullptr && (p.ldr & 3)))) return PM_E_SHAPE;
   PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_DENSE>(p, flags, (hipStream_t)stream)));
 }
 
@@ -1350,6 +1446,7 @@ extern "C" int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const f
   p.zero = zero_page;
   p.a_bytes = ((F * H * W - 1) * ldx + Cin) * ((flags & PM_FLAG_A_F32) ? 4 : 2);
   plan_split(p, workspace, workspace_bytes);
+  if (p.colstats != nullptr && p.splits > 1 && ((p.ldc & 3) || (p.R != nullptr && (p.ldr & 3)))) return PM_E_SHAPE;
   if (!upsample2x && (Cin % BK) == 0)
     PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_CONV3X3_FAST>(p, flags, (hipStream_t)stream)));
   PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_CONV3X3>(p, flags, (hipStream_t)stream)));
@@ -1379,12 +1476,20 @@ extern "C" int pm_conv_temporal_k3(const void* x, int64_t ldx, const void* halo_
   p.zero = zero_page;
   p.a_bytes = ((F * P - 1) * ldx + Cin) * ((flags & PM_FLAG_A_F32) ? 4 : 2);
   plan_split(p, workspace, workspace_bytes);
+  if (p.colstats != nullptr && p.splits > 1 && ((p.ldc & 3) || (p.R != nullptr && (p.ldr & 3)))) return PM_E_SHAPE;
   PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_CONVT3>(p, flags, (hipStream_t)stream)));
 }
 
 #ifdef PM_RING_PROF
 extern "C" void pm_debug_ring_prof(void* buf) { g_ring_prof = reinterpret_cast<long long*>(buf); }
 #endif
+
+extern "C" int pm_gemm_colstats_rows(int64_t M, int64_t N, int64_t K, int act, size_t workspace_bytes) {
+  int ktps;
+  const int s = choose_splits(M, N, K, act, &ktps);
+  const bool split = s > 1 && workspace_bytes >= (size_t)s * M * N * sizeof(float) && (N & 3) == 0 && act != PM_ACT_GEGLU;
+  return split ? 16 : 64;
+}
 
 extern "C" size_t pm_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int act) {
   int ktps;

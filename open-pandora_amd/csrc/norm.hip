@@ -132,12 +132,31 @@ __global__ __launch_bounds__(256) void gn_finalize_colstats_kernel(const float* 
   const int g = blockIdx.x, inst = blockIdx.y;
   const int cpg = C / groups;
   const int n = tpi * cpg;
+  // entry i = (row block t, channel c) = (i / cpg, i % cpg), walked with stride 256 by increments (no division
+  // in the loop) and four independent 8-byte loads in flight; per-thread order of addition is fixed
   float a = 0.f, b = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int t = i / cpg, c = i - t * cpg;
-    const float* src = colstats + (((int64_t)inst * tpi + t) * C + g * cpg + c) * 2;
-    a += src[0];
-    b += src[1];
+  const int dq = 256 / cpg, dr = 256 - dq * cpg;
+  int t = (int)threadIdx.x / cpg, c = (int)threadIdx.x - t * cpg;
+  const float* base = colstats + ((int64_t)inst * tpi * C + g * cpg) * 2;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    float2 v[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ok[u] = (i + 256 * u) < n;
+      v[u] = ok[u] ? *reinterpret_cast<const float2*>(base + ((int64_t)t * C + c) * 2) : make_float2(0.f, 0.f);
+      t += dq;
+      c += dr;
+      if (c >= cpg) {
+        c -= cpg;
+        ++t;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a += v[u].x;
+      b += v[u].y;
+    }
   }
   // fixed reduction tree (deterministic): xor-shuffle inside each wave, then the 4 wave sums in order
   a = wave_sum(a);

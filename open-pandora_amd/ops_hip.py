@@ -78,14 +78,14 @@ class HipOps:
     # blocks) and group; taken from the epilogue's column sums when every instance is a whole number of
     # 64-row blocks, else by the ordinary statistics pass over the output.
     def _stats_begin(self, M, n_out, stats, K=0):
+        """-> (colstats buffer, rows per block) or None when the epilogue cannot deliver the statistics."""
         if stats is None:
             return None
         NI, groups = stats[0], stats[1]
-        if M % NI or (M // NI) % 64 or n_out % groups:
+        rows = self.lib.pm_gemm_colstats_rows(M, n_out, K, 0, self.ws_bytes)  # 64 unsplit, 16 from the split-K reduce
+        if M % NI or (M // NI) % rows or M % rows or n_out % groups:
             return None
-        if self.ws_bytes and self.lib.pm_gemm_workspace_bytes(M, n_out, K, 0) > 0:
-            return None  # a split-K shape: its epilogue runs in the reduce pass, keep the separate statistics
-        return torch.empty((M // 64) * n_out * 2, dtype=torch.float32, device=self.device)
+        return torch.empty((M // rows) * n_out * 2, dtype=torch.float32, device=self.device), rows
 
     def _stats_end(self, out, col, stats):
         if stats is None:
@@ -94,9 +94,10 @@ class HipOps:
         if col is None:
             # (NI, groups, "lazy"): the caller only wants statistics that come for free from the epilogue
             return (out, None) if len(stats) > 2 else (out, self.groupnorm_stats(out, NI, groups))
+        buf, rows = col
         M, n_out = out.shape
         tot = torch.empty(NI, groups, 2, dtype=torch.float32, device=self.device)
-        rc = self.lib.pm_groupnorm_finalize_colstats(_ptr(col), _ptr(tot), M // 64, n_out, NI, groups, self._stream())
+        rc = self.lib.pm_groupnorm_finalize_colstats(_ptr(buf), _ptr(tot), M // rows, n_out, NI, groups, self._stream())
         capi.check(rc, "pm_groupnorm_finalize_colstats")
         return out, tot
 
@@ -112,7 +113,7 @@ class HipOps:
         rc = self.lib.pm_gemm(_ptr(a), self._rows(a, True), _ptr(w), K, _ptr(bias),
                               _ptr(residual), residual.stride(0) if residual is not None else 0,
                               _ptr(out), out.stride(0), M, N, K, capi.ACT_CODES[act], flags, self.dt,
-                              _ptr(self.workspace), self.ws_bytes, _ptr(col), self._stream())
+                              _ptr(self.workspace), self.ws_bytes, _ptr(col[0] if col else None), self._stream())
         capi.check(rc, f"pm_gemm M={M} N={N} K={K}")
         return self._stats_end(out, col, stats)
 
@@ -130,7 +131,7 @@ class HipOps:
                                     residual.stride(0) if residual is not None else 0, _ptr(out),
                                     out.stride(0), F, H, W, cin, cout, stride, int(upsample), int(pad_lo),
                                     _ptr(self.zero_page), flags, self.dt, _ptr(self.workspace),
-                                    self.ws_bytes, _ptr(col), self._stream())
+                                    self.ws_bytes, _ptr(col[0] if col else None), self._stream())
         capi.check(rc, f"pm_conv2d_3x3 F={F} H={H} W={W} Cin={cin} Cout={cout}")
         return self._stats_end(out, col, stats)
 
@@ -149,7 +150,7 @@ class HipOps:
                                           residual.stride(0) if residual is not None else 0,
                                           _ptr(out), out.stride(0), F, P, cin, cout,
                                           _ptr(self.zero_page), flags, self.dt, _ptr(self.workspace),
-                                          self.ws_bytes, _ptr(col), self._stream())
+                                          self.ws_bytes, _ptr(col[0] if col else None), self._stream())
         capi.check(rc, f"pm_conv_temporal_k3 F={F} P={P} Cin={cin} Cout={cout}")
         return self._stats_end(out, col, stats)
 

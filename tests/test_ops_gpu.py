@@ -514,3 +514,29 @@ def test_fused_groupnorm_statistics(hip_ops_factory, dtype):
     xr = rnd(3 * 100, 64, dtype=dtype, seed=9)
     out, tot = ops.gemm(xr.cuda(), rnd(64, 64, dtype=dtype, seed=10).cuda(), stats=(3, 32))
     assert tot.shape == (3, 32, 2) and rel_err(tot, ops.groupnorm_stats(out, 3)) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fused_stats_from_the_splitk_reduce(hip_ops_factory, dtype):
+    """Shapes that split over K emit the GroupNorm column sums from the reduce pass (16-row blocks): the deep
+    levels' convs.  Totals must equal a statistics pass over the stored output; per-frame works when a frame is a
+    whole number of 16-row blocks (160 pixels at level 2)."""
+    ops = hip_ops_factory(dtype)
+    F, H, W, C = 16, 10, 16, 256  # 2560 rows, 160 per frame; K = 2304: few tiles, long K -> split
+    assert ops.lib.pm_gemm_colstats_rows(F * H * W, C, 9 * C, 0, ops.ws_bytes) == 16
+    x = rnd(F * H * W, C, dtype=dtype, seed=1)
+    wp = rnd(C, 9 * C, dtype=dtype, scale=(9 * C) ** -0.5, seed=2)
+    b = rnd(C, dtype=torch.float32, seed=3)
+    res = rnd(F * H * W, C, dtype=torch.float32, seed=4)
+    for NI in (1, F):
+        out, tot = ops.conv3x3(x.cuda(), wp.cuda(), b.cuda(), F, H, W, residual=res.cuda(), stream=True, stats=(NI, 32))
+        want_out, want_tot = REF.conv3x3(x, wp, b, F, H, W, residual=res, stats=(NI, 32))
+        assert rel_err(out, want_out) <= TOL[dtype]
+        assert tot.shape == (NI, 32, 2) and rel_err(tot, ops.groupnorm_stats(out, NI)) <= 2e-6
+    xt = rnd(16 * 40, 1280, dtype=dtype, seed=5)  # temporal conv at the deepest level: 640 rows
+    wt = rnd(256, 3 * 1280, dtype=dtype, scale=3840 ** -0.5, seed=6)
+    out, tot = ops.conv_t3(xt.cuda(), wt.cuda(), None, 16, 40, stream=True, stats=(1, 32))
+    assert rel_err(tot, ops.groupnorm_stats(out, 1)) <= 2e-6
+    out, tot = ops.gemm(xt.cuda(), wt[:, :1280].contiguous().cuda(), stats=(1, 32))  # 16-bit output
+    assert rel_err(tot, ops.groupnorm_stats(out, 1)) <= 1e-3
