@@ -28,15 +28,20 @@ def test_wire_formats_round_trip():
                "video_model.lm_head.weight": torch.zeros(2, 2)}
     legacy = {"state_dict": {"model.diffusion_model." + k.replace("fps_embedding", "framestride_embed"): v
                              for k, v in usd.items()}}
+    def poison(m):  # so that a load that skipped a tensor cannot pass the equality check below
+        with torch.no_grad():
+            for p in m.parameters():
+                p.fill_(float("nan"))
+
     for blob in (lightning, deepspeed, pandora, legacy, usd):
-        u2, _ = _models()
-        res = checkpoint.load_unet(u2, blob)
+        poison(unet)
+        res = checkpoint.load_unet(unet, blob)
         assert not res.missing_keys and not res.unexpected_keys
-        assert all(torch.equal(u2.state_dict()[k], usd[k]) for k in usd)
+        assert all(torch.equal(unet.state_dict()[k], usd[k]) for k in usd)
     for blob in (lightning, deepspeed, pandora, asd):
-        _, a2 = _models()
-        res = checkpoint.load_autoencoder(a2, blob)
+        poison(ae)
+        res = checkpoint.load_autoencoder(ae, blob)
         assert not res.missing_keys and not res.unexpected_keys
-        assert all(torch.equal(a2.state_dict()[k], asd[k]) for k in asd)
+        assert all(torch.equal(ae.state_dict()[k], asd[k]) for k in asd)
     parts = checkpoint.split_checkpoint(pandora)
     assert list(parts["rest"]) == ["video_model.lm_head.weight"]
