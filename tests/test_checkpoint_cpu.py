@@ -3,7 +3,7 @@
 load into the drop-in U-Net / AutoencoderKL (inference.py:27-52, tools/ckpt2bin.py:14, model.py:599)."""
 import torch
 
-from open_pandora_amd import checkpoint, synth
+from open_pandora_amd import checkpoint
 from open_pandora_amd.autoencoder import DDCONFIG, AutoencoderKL
 from open_pandora_amd.unet import UNetModel
 from test_oracle_golden import RH_KW
@@ -17,8 +17,9 @@ def _models():
 
 def test_wire_formats_round_trip():
     unet, ae = _models()
-    usd = synth.synth_state_dict(unet, seed=1)
-    asd = synth.synth_state_dict(ae, seed=2)
+    g = torch.Generator().manual_seed(1)
+    usd = {k: torch.randn(v.shape, generator=g) for k, v in unet.state_dict().items()}
+    asd = {k: torch.randn(v.shape, generator=g) for k, v in ae.state_dict().items()}
     lightning = {"state_dict": {**{"model.diffusion_model." + k: v for k, v in usd.items()},
                                 **{"first_stage_model." + k: v for k, v in asd.items()},
                                 "cond_stage_model.dummy": torch.zeros(1), "scale_arr": torch.zeros(3)}}
