@@ -38,11 +38,13 @@ def test_wire_formats_round_trip():
         poison(unet)
         res = checkpoint.load_unet(unet, blob)
         assert not res.missing_keys and not res.unexpected_keys
-        assert all(torch.equal(unet.state_dict()[k], usd[k]) for k in usd)
+        cur = unet.state_dict()
+        assert all(torch.equal(cur[k], usd[k]) for k in usd)
     for blob in (lightning, deepspeed, pandora, asd):
         poison(ae)
         res = checkpoint.load_autoencoder(ae, blob)
         assert not res.missing_keys and not res.unexpected_keys
-        assert all(torch.equal(ae.state_dict()[k], asd[k]) for k in asd)
+        cur = ae.state_dict()
+        assert all(torch.equal(cur[k], asd[k]) for k in asd)
     parts = checkpoint.split_checkpoint(pandora)
     assert list(parts["rest"]) == ["video_model.lm_head.weight"]
