@@ -43,6 +43,7 @@ struct GemmParams {
   const void* halo_hi;
   const void* zero;
   int64_t a_bytes;  // conv modes: bytes of the input tensor reachable from A (bound of the buffer descriptor)
+  int64_t tap_a[9], tap_w[9];  // fast 3x3 conv: per tap, byte shift of the A base and byte offset of the W K-tile (channel 0)
 #ifdef PM_RING_PROF
   long long* prof;  // [grid][8 waves][4] cycle sums (tools/ring_prof.py)
 #endif
@@ -826,6 +827,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
     int a_y[4], a_x[4];
     uint32_t inv[4] = {0u, 0u, 0u, 0u};  // conv modes: per row, the taps that are zero padding
     int tap_s = 0, ch_s = 0;
+    int64_t nxt_a = 0, nxt_w = 0;  // fast conv: table entries of the K-step about to be issued
     int l_round = 0, l_kt = 0, l_kt1 = 0;
     auto loader_begin = [&]() -> bool {
       const int w = work_id(l_round);
@@ -875,9 +877,14 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
         const int chunk = l_kt / 9;
         tap_s = l_kt - chunk * 9;
         ch_s = chunk * BK;
-      } else if (AMODE != A_DENSE) {
-        tap_s = (l_kt * BK) / p.Cin;
-        ch_s = l_kt * BK - tap_s * p.Cin;
+        nxt_a = p.tap_a[tap_s];
+        nxt_w = p.tap_w[tap_s];
+      } else if (AMODE != A_DENSE) {  // temporal: chunk-major too (frames f-1, f, f+1 per 64-channel chunk), same table
+        const int chunk = l_kt / 3;
+        tap_s = l_kt - chunk * 3;
+        ch_s = chunk * BK;
+        nxt_a = p.tap_a[tap_s];
+        nxt_w = p.tap_w[tap_s];
       }
       return true;
     };
@@ -889,12 +896,14 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
       if (AMODE == A_DENSE) {
         ab = Ab + (int64_t)kt * (BK * 2);
       } else if (AMODE == A_CONV3X3_FAST) {
-        dy = tap_s / 3;
-        dx = tap_s - dy * 3;
-        wb = Wb + ((int64_t)tap_s * p.Cin + ch_s) * 2;
-        ab = Ab + ((int64_t)((dy - 1) * p.Win + (dx - 1)) * p.lda + ch_s) * 2;
+        // per-tap A shift / W offset come from a host-filled table in the kernel arguments (scalar loads by a
+        // uniform index, fetched one K-step ahead at the end of the previous call): the lone loader wave spent
+        // ~150 cycles per K-step on the division by 3 and the 64-bit multiply chains that stood here
+        wb = Wb + nxt_w + (int64_t)ch_s * 2;
+        ab = Ab + nxt_a + (int64_t)ch_s * 2;
       } else {
-        ab = Ab + ((int64_t)(tap_s - 1) * p.P * p.lda + ch_s) * 2;
+        wb = Wb + nxt_w + (int64_t)ch_s * 2;
+        ab = Ab + nxt_a + (int64_t)ch_s * 2;
         hlo = p.halo_lo ? reinterpret_cast<const char*>(p.halo_lo) + (int64_t)ch_s * 2 : nullptr;
         hhi = p.halo_hi ? reinterpret_cast<const char*>(p.halo_hi) + (int64_t)ch_s * 2 : nullptr;
       }
@@ -922,6 +931,8 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
           if (AMODE == A_DENSE) {
             src = ab + a_off[j];
           } else if (AMODE == A_CONV3X3_FAST) {
+            dy = tap_s / 3;
+            dx = tap_s - dy * 3;
             const bool ok = (unsigned)(a_y[j] + dy - 1) < (unsigned)p.Hv && (unsigned)(a_x[j] + dx - 1) < (unsigned)p.Wv;
             src = ok ? ab + a_off[j] : zero;
           } else {
@@ -942,12 +953,15 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
           tap_s = 0;
           ch_s += BK;
         }
+        nxt_a = p.tap_a[tap_s];
+        nxt_w = p.tap_w[tap_s];
       } else if (AMODE != A_DENSE) {
-        ch_s += BK;
-        if (ch_s >= p.Cin) {
-          ch_s -= p.Cin;
-          ++tap_s;
+        if (++tap_s == 3) {
+          tap_s = 0;
+          ch_s += BK;
         }
+        nxt_a = p.tap_a[tap_s];
+        nxt_w = p.tap_w[tap_s];
       }
     };
     bool l_valid = loader_begin();
@@ -1445,6 +1459,10 @@ extern "C" int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const f
   p.Ho = (int)Ho; p.Wo = (int)Wo; p.stride = stride; p.ups = upsample2x ? 1 : 0; p.pad = pad_lo;
   p.zero = zero_page;
   p.a_bytes = ((F * H * W - 1) * ldx + Cin) * ((flags & PM_FLAG_A_F32) ? 4 : 2);
+  for (int t = 0; t < 9; ++t) {
+    p.tap_a[t] = ((int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * ldx * 2;
+    p.tap_w[t] = (int64_t)t * Cin * 2;
+  }
   plan_split(p, workspace, workspace_bytes);
   if (p.colstats != nullptr && p.splits > 1 && ((p.ldc & 3) || (p.R != nullptr && (p.ldr & 3)))) return PM_E_SHAPE;
   if (!upsample2x && (Cin % BK) == 0)
@@ -1475,6 +1493,10 @@ extern "C" int pm_conv_temporal_k3(const void* x, int64_t ldx, const void* halo_
   p.Cin = (int)Cin; p.F = (int)F; p.P = (int)P; p.halo_lo = halo_lo; p.halo_hi = halo_hi;
   p.zero = zero_page;
   p.a_bytes = ((F * P - 1) * ldx + Cin) * ((flags & PM_FLAG_A_F32) ? 4 : 2);
+  for (int t = 0; t < 3; ++t) {
+    p.tap_a[t] = (int64_t)(t - 1) * P * ldx * 2;
+    p.tap_w[t] = (int64_t)t * Cin * 2;
+  }
   plan_split(p, workspace, workspace_bytes);
   if (p.colstats != nullptr && p.splits > 1 && ((p.ldc & 3) || (p.R != nullptr && (p.ldr & 3)))) return PM_E_SHAPE;
   PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_CONVT3>(p, flags, (hipStream_t)stream)));
