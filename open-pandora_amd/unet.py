@@ -384,7 +384,7 @@ class UNetModel(nn.Module):
             c.stats[out.data_ptr()] = (tot, tuple(out.shape))
         return out
 
-    def _res_block(self, c, mod, x):
+    def _res_block(self, c, mod, x, out=None):
         ops, e = c.ops, c.w[self._names[mod]]
         P = c.H * c.W
         h = self._gn(c, x, e["gn1"], 1e-5, True, True)
@@ -396,7 +396,7 @@ class UNetModel(nn.Module):
         skip = x if e["skip"] is None else ops.gemm(x, e["skip"][0], e["skip"][1], stream=True)
         if not mod.use_temporal_conv:
             return self._keep_stats(c, ops.conv3x3(h, e["conv2"][0], e["conv2"][1], c.F, c.H, c.W, residual=skip,
-                                                   stream=True, stats=self._stream_stats(c)))
+                                                   stream=True, stats=self._stream_stats(c), out=out))
         h, tot = ops.conv3x3(h, e["conv2"][0], e["conv2"][1], c.F, c.H, c.W, residual=skip, stream=True,
                              stats=(1, 32))
         ident = h
@@ -409,7 +409,7 @@ class UNetModel(nn.Module):
                 h, tot = ops.conv_t3(t, wp, b, c.F, P, halo_lo=lo_h, halo_hi=hi_h, stream=True, stats=(1, 32))
             else:
                 h = self._keep_stats(c, ops.conv_t3(t, wp, b, c.F, P, residual=ident, halo_lo=lo_h, halo_hi=hi_h,
-                                                    stream=True, stats=self._stream_stats(c)))
+                                                    stream=True, stats=self._stream_stats(c), out=out))
         return h
 
     def _block(self, c, e, h, mod, temporal, F, P, gather=False):
@@ -444,7 +444,7 @@ class UNetModel(nn.Module):
         # (formed in f32 against the f32 stream) is stored as 16 bit
         return ops.gemm(g, e["ff2"][0], e["ff2"][1], residual=h)
 
-    def _transformer(self, c, mod, x, temporal):
+    def _transformer(self, c, mod, x, temporal, out=None):
         ops, e = c.ops, c.w[self._names[mod]]
         F, P = c.F, c.H * c.W
         h = self._gn(c, x, e["norm"], 1e-6, False, not temporal)
@@ -457,34 +457,53 @@ class UNetModel(nn.Module):
         h = self._block(c, e, h, mod, temporal, F, P, gather)
         if sharded:
             h = c.fp.pixels_to_frames(h, c.H * c.W)
-        return self._keep_stats(c, ops.gemm(h, *e["proj_out"], residual=x, stream=True, stats=self._stream_stats(c)))
+        return self._keep_stats(c, ops.gemm(h, *e["proj_out"], residual=x, stream=True, stats=self._stream_stats(c),
+                                            out=out))
 
-    def _run(self, c, seq, h):
-        for layer in seq:
+    def _run(self, c, seq, h, out=None):
+        """`out`: an f32 [rows, channels] view (row stride >= channels) the LAST op of the sequence writes into -
+        one half of a skip-concatenation buffer (forward), so that no torch.cat pass is needed."""
+        layers = list(seq)
+        for li, layer in enumerate(layers):
+            dst = out if li == len(layers) - 1 else None
             # the only statistics worth keeping are those of this layer's (live) input: an entry of a tensor
             # that has been freed meanwhile could otherwise meet a new tensor at the same address
             if c.stats:
                 c.stats = {k: v for k, v in c.stats.items() if k == h.data_ptr()}
             if isinstance(layer, ResBlock):
-                h = self._res_block(c, layer, h)
+                h = self._res_block(c, layer, h, dst)
             elif isinstance(layer, SpatialTransformer):
-                h = self._transformer(c, layer, h, False)
+                h = self._transformer(c, layer, h, False, dst)
             elif isinstance(layer, TemporalTransformer):
-                h = self._transformer(c, layer, h, True)
+                h = self._transformer(c, layer, h, True, dst)
             elif isinstance(layer, Downsample):
                 wp, b = c.w[self._names[layer]]
-                h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W, stride=2, stream=True)
+                h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W, stride=2, stream=True, out=dst)
                 c.H, c.W = (c.H + 1) // 2, (c.W + 1) // 2
             elif isinstance(layer, Upsample):
                 wp, b = c.w[self._names[layer]]
-                h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W, upsample=True, stream=True)
+                h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W, upsample=True, stream=True, out=dst)
                 c.H, c.W = 2 * c.H, 2 * c.W
             elif isinstance(layer, nn.Conv2d):  # stem
                 wp, b = c.w["stem"]
-                h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W, stream=True)
+                h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W, stream=True, out=dst)
             else:
                 raise TypeError(type(layer))
         return h
+
+    @staticmethod
+    def _out_geometry(seq, ch, H, W):
+        """(channels, H, W) of the stream after the layers of `seq` (static: from the module definitions)."""
+        for layer in seq:
+            if isinstance(layer, ResBlock):
+                ch = layer.out_channels
+            elif isinstance(layer, nn.Conv2d):
+                ch = layer.out_channels
+            elif isinstance(layer, Downsample):
+                H, W = (H + 1) // 2, (W + 1) // 2
+            elif isinstance(layer, Upsample):
+                H, W = 2 * H, 2 * W
+        return ch, H, W
 
     def _embed(self, c, timesteps, fs):
         ops, W = c.ops, c.w
@@ -531,18 +550,35 @@ class UNetModel(nn.Module):
             h = ops.pack_input(x[0].reshape(cin, t, hh * ww).contiguous(), None)
         else:
             h = x[0].reshape(cin, t, hh * ww).permute(1, 2, 0).reshape(t * hh * ww, cin).to(ops.dtype).contiguous()
-        hs = []
+        # Skip concatenations without a copy pass: decoder block k reads cat([h, skip_k]) (openaimodel3d.py:598-600).
+        # Its input buffer [rows, C_h + C_skip] is allocated when the encoder produces skip_k: the encoder block's last
+        # op writes the right half (and the encoder simply continues on that strided view), the op that produces the
+        # decoder's h writes the left half.
+        nblk = len(self.output_blocks)
+        cat_in = [blk[0].channels for blk in self.output_blocks]  # input channels of every decoder block
+        bufs = []
+        ch = None
         for i, module in enumerate(self.input_blocks):
-            h = self._run(c, module, h)
-            if i == 0 and self.addition_attention:
-                h = self._run(c, self.init_attn, h)
-            hs.append((h, c.H, c.W))
-        h = self._run(c, self.middle_block, h)
-        for module in self.output_blocks:
-            skip, sh, sw = hs.pop()
-            assert (sh, sw) == (c.H, c.W)
-            h = torch.cat([h, skip], dim=1)
-            h = self._run(c, module, h)
+            seqs = [module] + ([self.init_attn] if i == 0 and self.addition_attention else [])
+            gh, gw = c.H, c.W
+            for sq in seqs:
+                ch, gh, gw = self._out_geometry(sq, ch, gh, gw)
+            total = cat_in[nblk - 1 - i]
+            buf = torch.empty(c.F * gh * gw, total, dtype=torch.float32, device=h.device)
+            for si, sq in enumerate(seqs):
+                h = self._run(c, sq, h, buf[:, total - ch:] if si == len(seqs) - 1 else None)
+            assert h.data_ptr() == buf[:, total - ch:].data_ptr() and (c.H, c.W) == (gh, gw)
+            bufs.append((buf, total - ch, c.H, c.W))
+        buf, c_h, sh, sw = bufs.pop()
+        h = self._run(c, self.middle_block, h, buf[:, :c_h])
+        for k, module in enumerate(self.output_blocks):
+            assert (sh, sw) == (c.H, c.W) and h.data_ptr() == buf.data_ptr()
+            h = buf  # = cat([h, skip], dim=1)
+            if k + 1 < nblk:
+                buf, c_h, sh, sw = bufs.pop()
+                h = self._run(c, module, h, buf[:, :c_h])
+            else:
+                h = self._run(c, module, h)
         h = self._gn(c, h, c.w["out_gn"], 1e-5, True, True)
         y = ops.conv3x3(h, c.w["out_conv"][0], c.w["out_conv"][1], c.F, c.H, c.W, stream=True)
         return ops.unpack_output(y, t, hh * ww).reshape(1, self.out_channels, t, hh, ww)
