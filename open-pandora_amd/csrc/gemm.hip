@@ -178,11 +178,46 @@ __device__ __forceinline__ void store_fast(const GemmParams& p, f32x4 (&acc)[4][
   }
 }
 
+// Residual prefetch: when the epilogue is "+ bias, + residual, store" (no activation, unsplit, 8-column vectors),
+// the accumulators START from the residual instead of zero: its loads are issued at tile start and land behind the
+// K loop instead of stalling the epilogue (these GEMMs stream A, residual and output once: HBM-latency-bound), and
+// the epilogue then skips the add.  Returns whether it did (the caller zero-fills otherwise).
+template <typename T>
+__device__ __forceinline__ bool residual_into_acc(const GemmParams& p, f32x4 (&acc)[4][4], int m0, int n0, int wm,
+                                                  int wn, int fr, int fq) {
+  if (p.R == nullptr || p.splits > 1 || p.act != PM_ACT_NONE || (p.N & 7) || (p.ldc & 7) || (p.ldr & 7)) return false;
+  const bool f32res = p.res32 != 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + wm * 64 + i * 16 + fr;
+    if (m > p.M - 1) m = p.M - 1;
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      int n = n0 + wn * 64 + jp * 32 + fq * 8;
+      if (n > p.N - 8) n = p.N - 8;
+      if (f32res) {
+        const float* rp = reinterpret_cast<const float*>(p.R) + (int64_t)m * p.ldr + n;
+        acc[i][2 * jp] = *reinterpret_cast<const f32x4*>(rp);
+        acc[i][2 * jp + 1] = *reinterpret_cast<const f32x4*>(rp + 4);
+      } else {
+        Pack8<T> rv;
+        rv.u = ld_global16(reinterpret_cast<const T*>(p.R) + (int64_t)m * p.ldr + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc[i][2 * jp][r] = to_f32(rv.e[r]);
+          acc[i][2 * jp + 1][r] = to_f32(rv.e[4 + r]);
+        }
+      }
+    }
+  }
+  return true;
+}
+
 // rows m0 + wm*64 + i*16 + fr, columns n0 + wn*64 + ...; sblock = index of this wave's 64-row block in colstats
 template <typename T, bool FAST = true>
 __device__ __forceinline__ void epilogue_regs(const GemmParams& p, f32x4 (&acc)[4][4], const float (&bv)[4][4],
                                               int m0, int n0, int wm, int wn, int fr, int fq, int sblock,
-                                              int split) {
+                                              int split, bool res_done = false) {
   const bool partial = p.splits > 1;
   // The MFMAs ran with the operands swapped (W fragment as "A"), so the accumulator tile is C^T: lane
   // (fr, fq) holds row m = i*16 + fr and, for column block j, the 4 CONSECUTIVE columns 4*fq .. 4*fq+3.
@@ -193,9 +228,9 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, f32x4 (&acc)[
   const bool geglu = (act == PM_ACT_GEGLU);
   const int nout = geglu ? (p.N >> 1) : p.N;
   T* __restrict__ Cg = reinterpret_cast<T*>(p.C);
-  const T* __restrict__ Rg = (partial || p.res32) ? nullptr : reinterpret_cast<const T*>(p.R);
+  const T* __restrict__ Rg = (partial || p.res32 || res_done) ? nullptr : reinterpret_cast<const T*>(p.R);
   float* __restrict__ Cf = partial ? p.ws + (int64_t)split * p.M * p.N : reinterpret_cast<float*>(p.C);
-  const float* __restrict__ Rf = (partial || !p.res32) ? nullptr : reinterpret_cast<const float*>(p.R);
+  const float* __restrict__ Rf = (partial || !p.res32 || res_done) ? nullptr : reinterpret_cast<const float*>(p.R);
   const bool out32 = partial || p.out32 != 0;
   const int64_t ldc = partial ? p.N : p.ldc;
   const bool want_stats = (p.colstats != nullptr) && !partial;
@@ -696,10 +731,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     const bool has_next = PERSIST && (w + G < nwork);
 
     f32x4 acc[4][4];
+    const bool res_done = residual_into_acc<T>(p, acc, m0, n0, wm, wn, fr, fq);
+    if (!res_done) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     float bv[4][4];  // bias of this lane's columns: requested now, needed in the epilogue
     load_bias_regs(p, bv, n0, wn, fq);
 
@@ -736,7 +774,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     }
     // ---------------- epilogue: registers -> global (no LDS staging, no barrier) ----------------
     // split-K slices store raw f32 partials into their slab; bias/act/residual run in the reduce pass
-    epilogue_regs<T>(p, acc, bv, m0, n0, wm, wn, fr, fq, mt * WMW + wm, split);
+    epilogue_regs<T>(p, acc, bv, m0, n0, wm, wn, fr, fq, mt * WMW + wm, split, res_done);
     if (!has_next) break;
     w += G;
   }
@@ -1056,10 +1094,13 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
     load_bias_regs(p, bv, n0, wn, fq);
 
     f32x4 acc[4][4];
+    const bool res_done = residual_into_acc<T>(p, acc, m0, n0, wm, wn, fr, fq);
+    if (!res_done) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     for (int kt = kt0; kt < kt1; ++kt) {
 #ifdef PM_RING_PROF
@@ -1116,7 +1157,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
 #endif
 
     // ---------------- epilogue of this wave's 64x64 quadrant (the loaders keep streaming the next tile) ----
-    epilogue_regs<T>(p, acc, bv, m0, n0, wm, wn, fr, fq, mt * 2 + wm, split);
+    epilogue_regs<T>(p, acc, bv, m0, n0, wm, wn, fr, fq, mt * 2 + wm, split, res_done);
 #ifdef PM_RING_PROF
     t_epi += clock64() - e0;
 #endif
