@@ -178,7 +178,7 @@ class TimestepEmbedSequential(nn.Sequential):
 # ------------------------------------------------------------------------------------------------
 class _Ctx:
     """Per-forward execution state."""
-    __slots__ = ("ops", "fp", "F", "H", "W", "emb_bias", "ctx_text", "ctx_img", "w", "stats")
+    __slots__ = ("ops", "fp", "F", "H", "W", "emb_bias", "ctx_text", "ctx_img", "w", "stats", "kv_text", "kv_img")
 
 
 class UNetModel(nn.Module):
@@ -348,6 +348,17 @@ class UNetModel(nn.Module):
         if self.fs_condition:
             W["fps_embedding"] = [lin(self.fps_embedding[0]), lin(self.fps_embedding[2])]
         self._names = {m: n for n, m in self.named_modules()}
+        # The text / image context is the same for every cross-attention block of a forward: ALL their k|v
+        # projections run as one GEMM per context kind at the top of forward (16 + 16 launches of a 77- / 256-row
+        # GEMM become 2); a block then reads its [rows, 2*inner] column slice of the result in place.
+        for key, cat_key in (("a2_kv", "kv_text_all"), ("a2_kv_ip", "kv_img_all")):
+            off, parts = 0, []
+            for name, e in W.items():
+                if isinstance(e, dict) and key in e:
+                    e[key + "_slice"] = (off, off + e[key].shape[0])
+                    off += e[key].shape[0]
+                    parts.append(e.pop(key))
+            W[cat_key] = torch.cat(parts, 0).contiguous() if parts else None
         self._packed = W
         for t in ([0], [self.default_fs]):  # warm the frequency-table cache for this device
             timestep_embedding(torch.tensor(t, device=dev), self.model_channels)
@@ -431,10 +442,12 @@ class UNetModel(nn.Module):
                     a = ops.attention(q, k, v, heads)
             else:  # spatial cross-attention: text keys shared by all frames + per-frame image keys
                 q = v3(ops.gemm(y, e["a2_q"]), inner)
-                kv_t = ops.gemm(c.ctx_text, e["a2_kv"]).view(1, -1, 2 * inner)
+                lo, hi = e["a2_kv_slice"]
+                kv_t = c.kv_text[:, lo:hi].unsqueeze(0)  # [1, 77, 2*inner] view of the batched projection
                 k2 = v2 = None
-                if "a2_kv_ip" in e:
-                    kv_i = ops.gemm(c.ctx_img, e["a2_kv_ip"]).view(F, -1, 2 * inner)
+                if "a2_kv_ip_slice" in e:
+                    lo, hi = e["a2_kv_ip_slice"]
+                    kv_i = c.kv_img[:, lo:hi].unflatten(0, (F, -1))  # [F, 16, 2*inner] view
                     k2, v2 = kv_i[..., :inner], kv_i[..., inner:]
                 a = ops.attention(q, kv_t[..., :inner], kv_t[..., inner:], heads, k2, v2, 1.0)
             h = ops.gemm(a.view(F * P, inner), *e[f"a{which}_out"], residual=h, stream=True)
@@ -544,6 +557,8 @@ class UNetModel(nn.Module):
             c.ctx_img = img.reshape(t * 16, -1).contiguous()
         else:
             raise NotImplementedError("context without per-frame image tokens")
+        c.kv_text = ops.gemm(c.ctx_text, c.w["kv_text_all"]) if c.w["kv_text_all"] is not None else None
+        c.kv_img = ops.gemm(c.ctx_img, c.w["kv_img_all"]) if c.w["kv_img_all"] is not None else None
         c.emb_bias = self._embed(c, timesteps, fs)
 
         if x.dtype == torch.float32:
