@@ -11,6 +11,8 @@
 //                      come from the row-major V tile through ds_read_b64_tr_b16.
 // Two key/value segments (text, image) are normalised independently and summed (attention.py:128-142).
 #include <stdlib.h>
+#include <math.h>
+#include <type_traits>
 #include "common.hpp"
 
 namespace pm {
@@ -27,6 +29,7 @@ struct AttnParams {
   int nseg;
   int Nq, heads, nqt;
   float scale_log2e;
+  int prescaled;  // attn_self_kernel: q already carries scale * log2(e) (scale_log2e == 1)
 };
 
 constexpr int KV_TILE = 64;
@@ -275,6 +278,249 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Single-segment attention (the spatial self-attention: 19 % of a 576x1024 forward's FLOPs), VALU diet.
+//
+// At head dim 64 a 32-query x 64-key tile is 16 MFMAs (512 matrix cycles) against 2048 scores of softmax, so
+// the kernel lives or dies by the vector instructions per score.  attn_kernel spends ~6.5 (max, scale-and-
+// subtract FMA, exp, sum, convert, rescale bookkeeping); this one ~3:
+//   * Q arrives pre-multiplied by scale*log2(e) (the host folds it into the to_q weights; otherwise the
+//     fragments are scaled once here), so scores are already in the base-2 domain: no per-score multiply;
+//   * the running maximum is subtracted BY THE MFMA: the S^T chain's initial accumulator is a register block
+//     holding -m (nm[]), so the chain ends in s - m and p = exp2(S') needs no subtraction either.  m is the
+//     "stale" maximum: it is only raised when a tile's scores exceed it by more than STALE_THR (p stays
+//     <= 2^STALE_THR: harmless for f32 accumulation and for the 16-bit P operand, whose relative precision
+//     does not depend on magnitude), which after the first tiles almost never happens, so the O/l rescale
+//     and the rewrite of nm[] leave the steady state: per score there remain 1/2 v_max3 (the check), v_exp,
+//     v_add (row sum) and 1/2 v_cvt_pk;
+//   * the first tile and a ragged last tile run a "careful" variant (exact maximum, key masking): none of
+//     that is in the hot loop;
+//   * 64 query rows per wave as two 32-row blocks whose chains are issued block after block
+//     (S'(0) | max(0) | S'(1) || exp(0) | max(1) | PV(0) || exp(1) | PV(1)), so one block's VALU work sits
+//     beside the other block's MFMAs inside one wave, on top of the overlap between the two waves of a SIMD.
+constexpr float STALE_THR = 6.0f;
+
+template <typename T, int QB, bool PIPE>
+__global__ __launch_bounds__(256, 2) void attn_self_kernel(const AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE_BYTES];  // K[2], V[2]
+  char* const Ks = smem;
+  char* const Vs = smem + 2 * KV_TILE_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, hh = lane >> 5;
+  int wg = blockIdx.x;
+  {  // XCD-aware: all query tiles of one (frame, head) run on one XCD (its K/V stays in that L2)
+    const int nwg = gridDim.x, qn = nwg >> 3, rn = nwg & 7, xcd = wg & 7;
+    wg = ((xcd < rn) ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (wg >> 3);
+  }
+  const int bh = wg / p.nqt;
+  const int qt = wg - bh * p.nqt;
+  const int b = bh / p.heads, head = bh - b * p.heads;
+
+  int qrow[QB];
+  bool q_valid[QB];
+  Pack8<T> qf[QB][4];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    qrow[qb] = qt * (128 * QB) + wave * (32 * QB) + qb * 32 + ql;
+    q_valid[qb] = qrow[qb] < p.Nq;
+    if (!q_valid[qb]) qrow[qb] = p.Nq - 1;
+    const T* qp = reinterpret_cast<const T*>(p.q) + (int64_t)b * p.q_bs + (int64_t)qrow[qb] * p.q_rs +
+                  head * 64 + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[qb][s].u = ld_global16(qp + 16 * s);
+  }
+  if (p.prescaled == 0) {  // (uniform) general callers: one extra 16-bit rounding of q * scale * log2(e)
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[qb][s].e[e] = from_f32<T>(to_f32(qf[qb][s].e[e]) * p.scale_log2e);
+  }
+
+  const int lr = tid >> 3;
+  const int Nk = p.Nk[0];
+  const char* const kbase = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.k[0]) + (int64_t)b * p.k_bs[0] + head * 64);
+  const char* const vbase = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.v[0]) + (int64_t)b * p.k_bs[0] + head * 64);
+  const uint32_t krs2 = (uint32_t)(p.k_rs[0] * 2);
+  const int nkt = (Nk + KV_TILE - 1) / KV_TILE;
+  const int kc = (tid & 7) ^ ((lr >> 1) & 7);           // source-side swizzles: see attn_kernel
+  const int vc = (tid & 7) ^ (((lr >> 1) & 1) << 2);
+  auto load_kv = [&](int kt, int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int key = kt * KV_TILE + lr + 32 * j;
+      if (key > Nk - 1) key = Nk - 1;
+      const int dst = buf * KV_TILE_BYTES + (32 * j + 8 * wave) * 128;
+      const uint32_t row = (uint32_t)key * krs2;
+      __builtin_amdgcn_global_load_lds((glb_void*)(kbase + (row + (uint32_t)kc * 16)), (lds_void*)(Ks + dst), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)(vbase + (row + (uint32_t)vc * 16)), (lds_void*)(Vs + dst), 16, 0, 0);
+    }
+  };
+
+  f32x16 oacc[QB][2], nm[QB];  // nm: every register = -m_run, the initial accumulator of the S^T chains
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    m_run[qb] = 0.f;
+    l_run[qb] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) nm[qb][r] = 0.f;
+    asm volatile("" : "+v"(nm[qb]));
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[qb][d][r] = 0.f;
+  }
+
+  // transposed-read lane coordinates of the V^T fragments (see attn_kernel)
+  const int trow = (lane & 15) >> 2;
+  const int tcol8 = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
+  const int tsub = (lane & 1) * 8;
+
+  // raise the stale maximum of block qb by the row maximum of the pending tile (mx: this lane's half)
+  auto raise = [&](int qb, f32x16 (&sacc)[2], float mx, bool first) {
+    float rmx = fmaxf(mx, other_half(mx));
+    if (!first) {
+      rmx = fmaxf(rmx, 0.f);  // never lower m: rows that did not outgrow it keep alpha == 1 exactly
+      const float alpha = __builtin_amdgcn_exp2f(-rmx);
+      l_run[qb] *= alpha;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[qb][d][r] *= alpha;
+    }
+    m_run[qb] += rmx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) nm[qb][r] = -m_run[qb];
+    // opaque to the optimiser: knowing the 16 registers equal, hipcc re-broadcasts them from one scalar in
+    // every tile (15 v_mov per block and tile - the very instructions this block exists to save)
+    asm volatile("" : "+v"(nm[qb]));
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kb][r] -= rmx;
+  };
+
+  // one K/V tile.  CAREFUL: exact maximum + key masking (first tile, ragged last tile).
+  auto tile = [&](int kt, int buf, auto careful_c) {
+    constexpr bool CAREFUL = decltype(careful_c)::value;
+    const char* ks = Ks + buf * KV_TILE_BYTES;
+    const char* vs = Vs + buf * KV_TILE_BYTES;
+    Pack8<T> pf[QB][4];
+    auto pv = [&](int qb) {  // O^T += V^T . P^T
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const int r0 = 16 * s4 + 4 * hh + trow;
+          const int r1 = r0 + 8;
+          const int ch = db * 4 + tcol8;
+          const int off0 = r0 * 128 + ((ch ^ (((r0 >> 1) & 1) << 2)) << 4) + tsub;
+          const int off1 = r1 * 128 + ((ch ^ (((r1 >> 1) & 1) << 2)) << 4) + tsub;
+          typename Vec<T>::v8 vf = tr_pair<T>(vs, off0, off1);
+          oacc[qb][db] = mfma32(vf, pf[qb][s4].v, oacc[qb][db]);
+        }
+      }
+    };
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      // ---- S'^T = K . Q'^T - m : the chain starts from nm (K fragments are re-read per block: LDS reads are
+      // cheap here, registers are not) ----
+      f32x16 sacc[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int row = kb * 32 + ql;
+        Pack8<T> kf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int chunk = 2 * s + hh;
+          kf[s].u = *reinterpret_cast<const u32x4*>(ks + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+        }
+        sacc[kb] = mfma32(kf[0].v, qf[qb][0].v, nm[qb]);
+#pragma unroll
+        for (int s = 1; s < 4; ++s) sacc[kb] = mfma32(kf[s].v, qf[qb][s].v, sacc[kb]);
+      }
+      if constexpr (PIPE) {
+        if (qb > 0) pv(qb - 1);  // the previous block's P.V sits between this block's S' chain and its softmax
+      }
+      if constexpr (CAREFUL) {
+        if (kt * KV_TILE + KV_TILE > Nk) {
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = kt * KV_TILE + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+              if (key >= Nk) sacc[kb][r] = -INFINITY;
+            }
+        }
+      }
+      // ---- this lane's maximum over its 32 scores of the tile ----
+      float m0 = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) m0 = fmaxf(fmaxf(m0, sacc[0][r]), sacc[1][r]);
+      if constexpr (CAREFUL) {
+        raise(qb, sacc, m0, kt == 0);
+      } else {
+        if (__builtin_amdgcn_ballot_w64(m0 > STALE_THR) != 0) raise(qb, sacc, m0, false);
+      }
+      // ---- p = 2^S', row sum, 16-bit P operand ----
+      float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pe = __builtin_amdgcn_exp2f(sacc[kb][r]);
+          ps[r & 3] += pe;
+          pf[qb][kb * 2 + (r >> 3)].e[r & 7] = from_f32<T>(pe);
+        }
+      l_run[qb] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+      if constexpr (!PIPE) {
+        pv(qb);
+        __builtin_amdgcn_sched_barrier(0);  // keep the blocks apart: interleaved, their live ranges spill
+      }
+    }
+    if constexpr (PIPE) pv(QB - 1);
+  };
+
+  load_kv(0, 0);
+  __syncthreads();  // drains the DMA (vmcnt) before the barrier
+  // three separate loops (careful first tile | fast tiles | careful ragged tile): with the two variants as the
+  // arms of one loop body hipcc copied the 16-register accumulator tuples at every merge (~50 v_mov per tile)
+  const int last_full = (Nk % KV_TILE == 0) ? nkt : nkt - 1;  // tiles [1, last_full) need no masking
+  if (nkt > 1) load_kv(1, 1);
+  tile(0, 0, std::true_type{});
+  __syncthreads();
+  for (int kt = 1; kt < last_full; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) load_kv(kt + 1, buf ^ 1);
+    tile(kt, buf, std::false_type{});
+    __syncthreads();
+  }
+  if (nkt > 1 && last_full < nkt) {
+    tile(nkt - 1, (nkt - 1) & 1, std::true_type{});
+  }
+
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const float l_tot = l_run[qb] + other_half(l_run[qb]);
+    const float inv = 1.0f / l_tot;
+    if (q_valid[qb]) {
+      T* op = reinterpret_cast<T*>(p.o) + (int64_t)b * p.o_bs + (int64_t)qrow[qb] * p.o_rs + head * 64;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          Pack4<T> ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov.e[e] = from_f32<T>(oacc[qb][db][4 * g + e] * inv);
+          *reinterpret_cast<u32x2*>(op + db * 32 + 8 * g + 4 * hh) = ov.u;
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Temporal self-attention: at every (pixel, head) a (Fq x Fk <= 16 x 16) attention over the frame
 // axis, head dim 64.  HBM-bound (0.1 % of the FLOPs) - the job is to touch q, k, v, o once with wide
 // loads and keep the arithmetic off the VALU:
@@ -392,6 +638,10 @@ __global__ __launch_bounds__(256) void tattn_kernel(const TAttnParams p) {
 
 using namespace pm;
 
+// kernel selection override for A/B measurements (tools/attn_bench.py); 0 = automatic.  Not part of the ABI.
+static int g_attn_variant = [] { const char* e = getenv("PANDORA_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
+extern "C" void pm_debug_attn_variant(int v) { g_attn_variant = v; }
+
 extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const void* k1,
                             const void* v1, int64_t k1_bs, int64_t k1_rs, int64_t Nk1,
                             const void* k2, const void* v2, int64_t k2_bs, int64_t k2_rs,
@@ -411,23 +661,35 @@ extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const voi
   p.nseg = k2 ? 2 : 1;
   p.Nq = (int)Nq; p.heads = (int)heads;
   p.scale_log2e = scale * 1.4426950408889634f;
-  // 64 query rows per wave (256 per workgroup) only for very large grids (measured: +2 % at N = 9216,
-  // slower below that because of the coarser tail)
-  static const bool allow_qb2 = [] { const char* e = getenv("PANDORA_ATTN_QB2"); return !(e && e[0] == '0'); }();
-  const bool qb2 = allow_qb2 && !k2 && ((Nq + 255) / 256) * B * heads >= 2048;
-  const int rows = qb2 ? 256 : 128;
-  p.nqt = (int)((Nq + rows - 1) / rows);
-  dim3 grid((unsigned)(p.nqt * B * heads));
-  if (qb2)
-    PM_DISPATCH_DTYPE(dtype, T,
-                      hipLaunchKernelGGL((attn_kernel<T, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
-                      return check_launch());
-  if (k2)
+  p.prescaled = fabsf(p.scale_log2e - 1.0f) < 1e-6f ? 1 : 0;
+  if (k2) {
+    p.nqt = (int)((Nq + 127) / 128);
+    dim3 grid((unsigned)(p.nqt * B * heads));
     PM_DISPATCH_DTYPE(dtype, T,
                       hipLaunchKernelGGL((attn_kernel<T, 1, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
                       return check_launch());
+  }
+  // single segment.  64 query rows per wave (256 per workgroup) whenever that still gives every CU its two
+  // workgroups; 32 rows per wave below that (short sequences: finer tail)
+  const int variant = g_attn_variant;
+  const bool qb2 = variant == 2 || variant == 3 || (variant == 0 && ((Nq + 255) / 256) * B * heads >= 512);
+  const int rows = qb2 ? 256 : 128;
+  p.nqt = (int)((Nq + rows - 1) / rows);
+  dim3 grid((unsigned)(p.nqt * B * heads));
+  if (variant == 9)  // (kept for A/B runs: the round-1 kernel)
+    PM_DISPATCH_DTYPE(dtype, T,
+                      hipLaunchKernelGGL((attn_kernel<T, 1, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+                      return check_launch());
+  if (qb2 && variant == 3)
+    PM_DISPATCH_DTYPE(dtype, T,
+                      hipLaunchKernelGGL((attn_self_kernel<T, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+                      return check_launch());
+  if (qb2)
+    PM_DISPATCH_DTYPE(dtype, T,
+                      hipLaunchKernelGGL((attn_self_kernel<T, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+                      return check_launch());
   PM_DISPATCH_DTYPE(dtype, T,
-                    hipLaunchKernelGGL((attn_kernel<T, 1, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+                    hipLaunchKernelGGL((attn_self_kernel<T, 1, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
                     return check_launch());
 }
 

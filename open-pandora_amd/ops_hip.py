@@ -5,6 +5,8 @@ the stream owner) and enqueues exactly one or two kernels from libpandora_mi355x
 current stream.  Activations are channels-last token matrices [frames*H*W, C] in f16 or bf16.
 There is deliberately no CPU / eager fallback here.
 """
+import math
+
 import torch
 
 from . import capi
@@ -20,6 +22,10 @@ def _ptr(t):
 class HipOps:
     name = "hip"
     supports_graphs = True  # every op only enqueues kernels on the current stream: capturable
+    # pm_attention's single-segment kernel works in the base-2 domain on q * (64^-1/2 * log2 e).  A caller that
+    # owns the q projection folds this factor into its weights (UNetModel.prepare) and calls
+    # attention(..., prescaled=True); otherwise the kernel scales (and re-rounds) the q fragments itself.
+    q_prescale = 64 ** -0.5 * 1.4426950408889634
 
     def __init__(self, dtype=torch.bfloat16, device="cuda", workspace_mb=256):
         if dtype not in _DT:
@@ -215,9 +221,10 @@ class HipOps:
         return out
 
     # -- attention -------------------------------------------------------------------------------
-    def attention(self, q, k1, v1, heads, k2=None, v2=None, w2=1.0, out=None):
+    def attention(self, q, k1, v1, heads, k2=None, v2=None, w2=1.0, out=None, prescaled=False):
         """q [B, Nq, heads*64] view; kX/vX [B or 1, NkX, heads*64] views (last dim contiguous).
-        out = attn(q,k1,v1) + w2*attn(q,k2,v2), each softmax-normalised on its own."""
+        out = attn(q,k1,v1) + w2*attn(q,k2,v2), each softmax-normalised on its own.
+        prescaled: q already carries `q_prescale` (then softmax(q k^T 64^-1/2) == softmax_2(q' k^T))."""
         B, Nq, C = q.shape
         assert C == heads * 64 and q.stride(2) == 1 and q.dtype == self.dtype
 
@@ -232,7 +239,7 @@ class HipOps:
             bs2, rs2, n2 = kv(k2, v2)
         if out is None:
             out = self.empty(B, Nq, C)
-        scale = 64 ** -0.5
+        scale = math.log(2.0) if prescaled else 64 ** -0.5  # ln 2 * log2 e == 1: no scaling left in the kernel
         rc = self.lib.pm_attention(_ptr(q), q.stride(0), q.stride(1), _ptr(k1), _ptr(v1), bs1, rs1,
                                    n1, _ptr(k2), _ptr(v2), bs2, rs2, n2, float(w2), _ptr(out),
                                    out.stride(0), out.stride(1), B, heads, Nq, scale, self.dt,

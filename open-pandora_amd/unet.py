@@ -321,7 +321,14 @@ class UNetModel(nn.Module):
                 for i, ln in enumerate((blk.norm1, blk.norm2, blk.norm3), 1):
                     e[f"ln{i}"] = (f32(ln.weight), f32(ln.bias))
                 a1 = blk.attn1
-                e["a1_qkv"] = wt(torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0))
+                wq = a1.to_q.weight
+                # spatial self-attention: the softmax scale (and the base-2 conversion) ride on the q projection,
+                # folded into its weights in f32 before the one rounding to the kernel dtype (ops.q_prescale)
+                pre = getattr(ops, "q_prescale", None) if isinstance(mod, SpatialTransformer) else None
+                if pre is not None:
+                    wq = wq.detach().float() * pre
+                    e["a1_prescaled"] = True
+                e["a1_qkv"] = wt(torch.cat([wq, a1.to_k.weight.detach().float(), a1.to_v.weight.detach().float()], 0))
                 e["a1_out"] = lin(a1.to_out[0])
                 a2 = blk.attn2
                 if a2.self_attn:
@@ -438,6 +445,8 @@ class UNetModel(nn.Module):
                     if gather:  # frame-sharded without the pixel re-shard: all-gather K|V over frames
                         k, v = c.fp.gather_kv(qkv, inner, P)
                     a = ops.attention_temporal(q, k, v, heads)
+                elif which == 1 and e.get("a1_prescaled", False):
+                    a = ops.attention(q, k, v, heads, prescaled=True)
                 else:
                     a = ops.attention(q, k, v, heads)
             else:  # spatial cross-attention: text keys shared by all frames + per-frame image keys

@@ -438,10 +438,64 @@ def test_attention_self_64_rows_per_wave(hip_ops_factory, dtype):
     C = heads * 64
     qkv = rnd(B, N, 3 * C, dtype=torch.float32, scale=1.2, seed=1)
     qkv[3, 2090, C:2 * C] = 5 * qkv[3, 77, :C]  # key 2090 dominates query 77 of batch 3 (all heads)
+    qkv[5, 1000, C:2 * C] = 4 * qkv[5, 300, :C]  # a raise of the stale maximum in a fast (unmasked) tile
     qkv = qkv.to(dtype)
     want = REF.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
     d = qkv.cuda()
     got = ops.attention(d[..., :C], d[..., C:2 * C], d[..., 2 * C:], heads)
+    assert rel_err(got, want) <= TOL[dtype]
+
+
+def _attn_ref_base2(q, k, v, heads):
+    """softmax_2(q k^T) v per head in f64 (what pm_attention computes for scale = ln 2)."""
+    B, N, C = q.shape
+    sp = lambda t: t.double().reshape(t.shape[0], t.shape[1], heads, 64).permute(0, 2, 1, 3)
+    s = torch.einsum("bhid,bhjd->bhij", sp(q), sp(k)) * 0.6931471805599453
+    return torch.einsum("bhij,bhjd->bhid", torch.softmax(s, -1), sp(v)).permute(0, 2, 1, 3).reshape(B, N, C).float()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_attention_stale_max_paths(hip_ops_factory, dtype, variant):
+    """attn_self_kernel keeps a STALE running maximum that is only raised when a tile outgrows it by 2^6: force
+    every branch (cdna guide rule 26) - a raise in a fast (unmasked, not first) tile, twice for the same row; a
+    raise in the last fast tile; rows whose scores stay far BELOW the first tile's maximum; a ragged masked
+    last tile; rows that never raise - in all three kernel variants (32 / 64 rows per wave, pipelined P.V)."""
+    ops = hip_ops_factory(dtype)
+    B, heads = 2, 3
+    C = heads * 64
+    try:
+        for N in (384, 450):  # 6 whole tiles; 7 full + 1 ragged
+            q = rnd(B, N, C, dtype=torch.float32, seed=1)
+            k = rnd(B, N, C, dtype=torch.float32, seed=2)
+            v = rnd(B, N, C, dtype=torch.float32, seed=3)
+            k[0, 70] = 3 * q[0, 5]      # query 5: raise in tile 1 ...
+            k[0, 200] = 6 * q[0, 5]     # ... and again in tile 3 (both fast tiles)
+            k[1, 383] = 5 * q[1, 100]   # last key of tile 5
+            k[1, 10] = 8 * q[1, 300]    # dominant key in the FIRST tile: every later tile is far below m
+            k[0, N - 1] = 4 * q[0, 77]  # last key of the clip (masked tile when N = 450)
+            q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
+            want = REF.attention(q, k, v, heads)
+            ops.lib.pm_debug_attn_variant(variant)
+            got = ops.attention(q.cuda(), k.cuda(), v.cuda(), heads)
+            assert rel_err(got, want) <= TOL[dtype], (N, variant)
+            for (b, i) in ((0, 5), (1, 100), (1, 300), (0, 77), (0, 6)):  # the forced rows one by one
+                assert rel_err(got[b, i], want[b, i]) <= 2 * TOL[dtype], (N, variant, b, i)
+    finally:
+        ops.lib.pm_debug_attn_variant(0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_prescaled_q(hip_ops_factory, dtype):
+    """scale = ln 2 (scale * log2 e == 1): q is taken as already multiplied by 64^-1/2 log2 e, the kernel
+    applies no scaling of its own (the U-Net folds the factor into the to_q weights)."""
+    ops = hip_ops_factory(dtype)
+    B, heads, N = 3, 5, 333
+    C = heads * 64
+    q = rnd(B, N, C, dtype=dtype, scale=0.3, seed=1)
+    k, v = rnd(B, N, C, dtype=dtype, scale=1.2, seed=2), rnd(B, N, C, dtype=dtype, seed=3)
+    want = _attn_ref_base2(q, k, v, heads)
+    got = ops.attention(q.cuda(), k.cuda(), v.cuda(), heads, prescaled=True)
     assert rel_err(got, want) <= TOL[dtype]
 
 
