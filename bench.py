@@ -1,12 +1,22 @@
 """bench.py - denoising steps/sec of the DDIM / 3-D U-Net hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--res 320x512|576x1024] [--dtype bf16|f16]
+    python bench.py --gpus N --steps K --warmup W [--dtype bf16|f16] [--only 320x512|576x1024]
 
 One "step" = one DDIM step of a 16-frame clip with classifier-free guidance = 2 U-Net forwards
 (25.2 TFLOP at 320x512, 104.7 TFLOP at 576x1024) + the fused update kernel.  Inputs (latent, contexts,
-weights) are synthetic (seeded) and resident in HBM before the timed region.  Prints ONE JSON line on
-rank 0 (see the driver contract); extra objects: `roofline` (dominant kernel, HIP-event timed inside the
-timed region) and `cpu_baseline` (the CPU oracle = reference eager path restated, on the host cores).
+weights) are synthetic (seeded) and resident in HBM before the timed region.  ONE run measures BOTH
+BASELINE resolutions on the same 1.44 B-parameter U-Net: the headline line (`value`, `ms_per_step`) is
+BASELINE configs[1] (320x512), `res_576x1024` carries configs[2].  Prints ONE JSON line on rank 0; extra
+objects:
+  roofline            the kernel family with the largest share of the 320x512 step (chosen from the live
+                      measurement, not hard-coded), timed launch by launch with HIP events on the launch stream
+                      during eagerly issued steps of the same loop (the timed steps replay a HIP graph, whose
+                      nodes events cannot bracket); `families` lists every family's time / TFLOP/s;
+  roofline_attention  the spatial self-attention at N = 9216 tokens (72x128 latent, 16 frames x 5 heads),
+                      FLOPs 4 N^2 64 heads frames per launch (attention.py:81-144), in the 576x1024 loop;
+  cpu_baseline        the CPU oracle (f32 eager restatement of the reference) on the host cores.
+`roofline.traffic` is null: HBM-side bytes come from separate rocprofv3 --pmc passes (profiles/r02/), never from
+this run.
 """
 import argparse
 import json
@@ -21,44 +31,87 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_STEP = {"320x512": 25.21e12, "576x1024": 104.67e12}  # BASELINE.md §2 (2 forwards)
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16, MI355X_MICROARCH.md
+T = 16
+
+KERNELS = {
+    "gemm": "pm_gemm (dense nn.Linear / 1x1: gemm_kernel<A_DENSE> 2-stage, gemm_ring_kernel<A_DENSE>, split-K reduce)",
+    "conv3x3": "pm_conv2d_3x3 (gemm_ring_kernel<A_CONV3X3_FAST>; gemm_kernel for f32-operand / strided / upsampling convs)",
+    "conv_t3": "pm_conv_temporal_k3 (gemm_kernel / gemm_ring_kernel<A_CONVT3>)",
+    "attention": "pm_attention (attn_self_kernel: spatial self-attention; attn_kernel: text+image cross-attention)",
+}
 
 
 class TimedOps:
-    """HipOps proxy that brackets every launch of the dominant kernel (conv3x3 implicit GEMM) with
-    HIP events on the launch stream and counts its algorithmic FLOPs."""
+    """HipOps proxy that brackets every launch of the MFMA kernel families with HIP events on the launch
+    stream and counts their algorithmic FLOPs (2 M N K; attention 4 Nq Nk 64 heads B)."""
 
     def __init__(self, ops):
         self._ops = ops
-        self.events, self.flops, self.enabled = [], 0.0, False
+        self.enabled = False
+        self.reset()
+
+    def reset(self):
+        self.ev = {k: [] for k in KERNELS}
+        self.fl = {k: 0.0 for k in KERNELS}
+        self.attn_big = ([], 0.0)  # (events, flops) of the self-attention launches with Nq == Nk >= 9216
 
     def __getattr__(self, k):
         return getattr(self._ops, k)
 
-    def conv3x3(self, x, wp, bias, F, H, W, **kw):
+    def _timed(self, fam, flops, fn, *a, **kw):
         if not self.enabled:
-            return self._ops.conv3x3(x, wp, bias, F, H, W, **kw)
+            return fn(*a, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        y = self._ops.conv3x3(x, wp, bias, F, H, W, **kw)
+        y = fn(*a, **kw)
         e1.record()
-        self.events.append((e0, e1))
-        out = y[0] if isinstance(y, tuple) else y  # (out, GroupNorm totals) when stats are fused
-        self.flops += 2.0 * out.shape[0] * out.shape[1] * wp.shape[1]
-        return y
+        self.ev[fam].append((e0, e1))
+        self.fl[fam] += flops
+        return y, (e0, e1)
+
+    def gemm(self, a, w, *args, **kw):
+        r = self._timed("gemm", 2.0 * a.shape[0] * w.shape[0] * w.shape[1], self._ops.gemm, a, w, *args, **kw)
+        return r[0] if self.enabled else r
+
+    def conv3x3(self, x, wp, bias, F, H, W, **kw):
+        hv, wv = (2 * H, 2 * W) if kw.get("upsample") else (H, W)
+        s, pad = kw.get("stride", 1), kw.get("pad_lo", 1)
+        m = F * ((hv + pad - 2) // s + 1) * ((wv + pad - 2) // s + 1)
+        r = self._timed("conv3x3", 2.0 * m * wp.shape[0] * wp.shape[1], self._ops.conv3x3, x, wp, bias, F, H, W, **kw)
+        return r[0] if self.enabled else r
+
+    def conv_t3(self, x, wp, *args, **kw):
+        r = self._timed("conv_t3", 2.0 * x.shape[0] * wp.shape[0] * wp.shape[1], self._ops.conv_t3, x, wp, *args, **kw)
+        return r[0] if self.enabled else r
+
+    def attention(self, q, k1, v1, heads, k2=None, v2=None, *args, **kw):
+        B, nq, _ = q.shape
+        nk = k1.shape[1] + (0 if k2 is None else k2.shape[1])
+        fl = 4.0 * nq * nk * 64 * heads * B
+        r = self._timed("attention", fl, self._ops.attention, q, k1, v1, heads, k2, v2, *args, **kw)
+        if not self.enabled:
+            return r
+        if k2 is None and nq == k1.shape[1] and nq >= 9216:
+            self.attn_big[0].append(r[1])
+            self.attn_big = (self.attn_big[0], self.attn_big[1] + fl)
+        return r[0]
 
     def summary(self):
-        ms = sum(a.elapsed_time(b) for a, b in self.events)
-        n = max(1, len(self.events))
-        return ms, n, self.flops
+        out = {}
+        for fam in KERNELS:
+            ms = sum(a.elapsed_time(b) for a, b in self.ev[fam])
+            out[fam] = {"ms": ms, "launches": len(self.ev[fam]), "flops": self.fl[fam]}
+        ev, fl = self.attn_big
+        big = {"ms": sum(a.elapsed_time(b) for a, b in ev), "launches": len(ev), "flops": fl}
+        return out, big
 
 
-def cpu_baseline(pm, res, ins, cond):
+def cpu_baseline(unet, res, ins):
     """One U-Net forward of the oracle (f32 eager restatement of the reference) on the host cores."""
     from oracle import unet_ref
-    unet = pm.model.diffusion_model
     sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
     x = torch.cat([ins["x_T"], ins["c_concat"]], 1).float().cpu()
-    ctx = cond["c_crossattn"][0].float().cpu()
+    ctx = ins["c_crossattn"].float().cpu()
     # eager PyTorch on many small ops scales negatively past ~16 threads (measured on the GPU box's
     # 2 x 64-core EPYC: 16 threads 3.8 s, 32: 5.2 s, 64: 11.6 s, 128: 25.7 s for the same forward)
     prev = torch.get_num_threads()
@@ -77,10 +130,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--res", default="320x512")
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--only", default=None, choices=[None, "320x512", "576x1024"],
+                    help="kernel-work runs: measure one resolution (the driver line always carries both)")
+    ap.add_argument("--res", default=None, help=argparse.SUPPRESS)  # (round-1 spelling of --only)
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     a = ap.parse_args()
+    only = a.only or a.res
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -99,85 +155,117 @@ def main():
 
     from open_pandora_amd import factory, synth
     from open_pandora_amd.ddim import DDIMSampler
+    from open_pandora_amd.ddpm import LatentVisualDiffusion
     from open_pandora_amd.ops_hip import HipOps
 
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     ops = TimedOps(HipOps(dt, dev))
-    pm = factory.build_diffusion(a.res, ops)
-    h, w = factory.RESOLUTIONS[a.res]["image_size"]
-    T = 16
+    pm0 = factory.build_diffusion("320x512", ops)  # the two shipped configs share the U-Net (1 516 tensors)
+    unet = pm0.model.diffusion_model
     fp = cfgp = None
     mode = "1 GPU"
     if world > 1:
         from open_pandora_amd.frame_parallel import make_hybrid
         fp, cfgp = make_hybrid(T)
-        pm.model.diffusion_model.bind(ops, fp)
+        unet.bind(ops, fp)
         fw = 1 if fp is None else fp.world
         mode = (f"{'cond/uncond branch pair x ' if cfgp is not None else ''}{fw}-way frame shards "
                 f"({T // fw} frames/GPU), RCCL: 1 output exchange/step"
-                + ("" if fp is None else " + (T,H,W)-GN all-reduce, temporal-conv halo P2P, temporal K/V all-gather"))
+                + ("" if fp is None else " + (T,H,W)-GN all-reduce, temporal-conv halo exchange, frames<->pixels "
+                                         "all-to-all around each TemporalTransformer"))
         # both partners of a CFG pair must draw the same DDIM noise for their (shared) frame shard
         torch.manual_seed(1234 + (0 if fp is None else fp.rank))
         torch.cuda.manual_seed(1234 + (0 if fp is None else fp.rank))
-    ins = synth.synth_inputs(h, w, T, seed=123)
-    cond = {"c_crossattn": [ins["c_crossattn"].to(dev)], "c_concat": [ins["c_concat"].to(dev)]}
-    uc = {"c_crossattn": [ins["uc_crossattn"].to(dev)], "c_concat": [ins["c_concat"].to(dev)]}
-    x = ins["x_T"].to(dev)
-    if fp is not None:
-        cond["c_concat"] = [fp.shard_frames(cond["c_concat"][0])]
-        uc["c_concat"] = [fp.shard_frames(uc["c_concat"][0])]
-        x = fp.shard_frames(x)
-    fs = torch.tensor([15], device=dev)
-    S = 50
-    smp = DDIMSampler(pm, cfg_parallel=cfgp)
-    smp.make_schedule(S, "uniform_trailing", 1.0, verbose=False)
-    order = list(reversed(range(S)))  # index of the i-th loop iteration
-
-    def run(n, start):
-        nonlocal x
-        for j in range(n):
-            index = order[(start + j) % S]
-            step = int(smp.ddim_timesteps[index])
-            ts = torch.full((1,), step, device=dev, dtype=torch.long)
-            x, _ = smp.p_sample_ddim(x, cond, ts, index, unconditional_guidance_scale=4.0,
-                                     unconditional_conditioning=uc, fs=fs, step=step, want_x0=False)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    run(a.warmup, 0)
-    barrier()
-    t0 = time.perf_counter()
-    run(a.steps, a.warmup)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # Roofline leg: the timed steps replay a HIP graph (events cannot bracket nodes of a captured
-    # graph), so the dominant kernel is timed right after, live, with HIP events around every one of
-    # its launches on the launch stream during two more eagerly launched steps of the same loop.
-    smp.use_graph = False
-    run(1, a.warmup + a.steps)
-    ops.enabled = True
-    run(2, a.warmup + a.steps + 1)
-    torch.cuda.synchronize()
-    ops.enabled = False
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = tt.item()
-    assert torch.isfinite(x).all(), "latent went non-finite"
+    def run_resolution(res, steps, warmup):
+        h, w = factory.RESOLUTIONS[res]["image_size"]
+        if res == "320x512":
+            pm = pm0
+        else:  # same U-Net behind the other yaml's shell (base_scale of the dynamic rescale, image size)
+            r = dict(factory.RESOLUTIONS[res])
+            r.pop("default_fs")
+            pm = LatentVisualDiffusion(unet, linear_start=0.00085, linear_end=0.012, timesteps=1000,
+                                       parameterization="v", rescale_betas_zero_snr=True, conditioning_key="hybrid",
+                                       use_dynamic_rescale=True, scale_factor=0.18215, channels=4, **r)
+        ins = synth.synth_inputs(h, w, T, seed=123)
+        cond = {"c_crossattn": [ins["c_crossattn"].to(dev)], "c_concat": [ins["c_concat"].to(dev)]}
+        uc = {"c_crossattn": [ins["uc_crossattn"].to(dev)], "c_concat": [ins["c_concat"].to(dev)]}
+        x = ins["x_T"].to(dev)
+        if fp is not None:
+            cond["c_concat"] = [fp.shard_frames(cond["c_concat"][0])]
+            uc["c_concat"] = [fp.shard_frames(uc["c_concat"][0])]
+            x = fp.shard_frames(x)
+        fs = torch.tensor([15], device=dev)
+        S = 50
+        smp = DDIMSampler(pm, cfg_parallel=cfgp)
+        smp.make_schedule(S, "uniform_trailing", 1.0, verbose=False)
+        order = list(reversed(range(S)))  # index of the i-th loop iteration
+
+        def run(n, start):
+            nonlocal x
+            for j in range(n):
+                index = order[(start + j) % S]
+                step = int(smp.ddim_timesteps[index])
+                ts = torch.full((1,), step, device=dev, dtype=torch.long)
+                x, _ = smp.p_sample_ddim(x, cond, ts, index, unconditional_guidance_scale=4.0,
+                                         unconditional_conditioning=uc, fs=fs, step=step, want_x0=False)
+
+        run(warmup, 0)
+        barrier()
+        t0 = time.perf_counter()
+        run(steps, warmup)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        # Roofline leg: the timed steps replay a HIP graph (events cannot bracket nodes of a captured graph), so
+        # the kernel families are timed right after, live, with HIP events around every one of their launches on
+        # the launch stream during two more, eagerly launched steps of the same loop.
+        smp.use_graph = False
+        run(1, warmup + steps)
+        ops.reset()
+        ops.enabled = True
+        run(2, warmup + steps + 1)
+        torch.cuda.synchronize()
+        ops.enabled = False
+        fams, big = ops.summary()
+        if world > 1:
+            tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            elapsed = tt.item()
+        assert torch.isfinite(x).all(), "latent went non-finite"
+        step_s = elapsed / steps
+        fam_out = {}
+        for k, v in fams.items():
+            tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
+            fam_out[k] = {"ms_per_step": v["ms"] / 2.0, "launches_per_step": v["launches"] // 2,
+                          "tflops": tf, "frac_of_peak": tf / MFMA_PEAK_TFLOPS,
+                          "share_of_step_time": (v["ms"] * 1e-3 / 2.0) / step_s}
+        return {"res": res, "latent": [T, h, w], "steps": steps, "elapsed": elapsed, "step_s": step_s,
+                "families": fam_out, "raw": fams, "attn_big": big, "x": x, "ins": ins}
+
+    results = {}
+    if only in (None, "320x512"):
+        results["320x512"] = run_resolution("320x512", a.steps, a.warmup)
+    if only in (None, "576x1024"):
+        s1024 = a.steps if only else max(3, min(a.steps, 10))
+        results["576x1024"] = run_resolution("576x1024", s1024, min(a.warmup, 2) if not only else a.warmup)
+    head = results.get("320x512") or results["576x1024"]
 
     # first-stage decode of the clip (the step after the loop): reported beside the loop
     decode_ms = None
-    if world == 1:
+    if world == 1 and "320x512" in results:
         from open_pandora_amd.autoencoder import AutoencoderKL
+        h, w = head["latent"][1:]
         with torch.device("meta"):
             ae = AutoencoderKL()
         ae.load_state_dict({k: synth.synth_tensor(k, tuple(v.shape), 20230211, dev) for k, v in ae.state_dict().items()},
                            assign=True)
         ae.bind(ops)
-        z = (0.18215 * x).contiguous()
+        z = (0.18215 * head["x"]).contiguous()
         ae.decode_first_stage(z)  # warm-up (weight packing)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -187,32 +275,53 @@ def main():
         assert frames.shape == (1, 3, T, 8 * h, 8 * w) and torch.isfinite(frames).all()
 
     if rank == 0:
-        ms, n, fl = ops.summary()
-        traffic = None  # per-launch HBM-side bytes of the dominant kernel, from the committed PMC passes
-        tj = os.path.join(ROOT, "profiles", "r01", "traffic.json")
-        if a.res == "320x512" and os.path.exists(tj):
-            with open(tj) as f:
-                traffic = json.load(f)["conv3x3"]["traffic_bytes"]
-        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        def roof(r):
+            """the family with the largest measured share of the step"""
+            fam = max(r["raw"], key=lambda k: r["raw"][k]["ms"])
+            v = r["raw"][fam]
+            ach = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
+            return {"bound": "mfma", "kernel": KERNELS[fam], "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                    "launches": v["launches"], "avg_launch_ms": v["ms"] / max(1, v["launches"]),
+                    "share_of_step_time": r["families"][fam]["share_of_step_time"],
+                    "chosen_by": "largest summed HIP-event time among the MFMA kernel families of this run",
+                    "families": r["families"]}
+
+        res = head["res"]
         out = {
-            "metric": "denoising_steps_per_sec", "value": a.steps / elapsed, "unit": "steps/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "metric": "denoising_steps_per_sec", "value": 1.0 / head["step_s"], "unit": "steps/s",
+            "n_gpus": world, "steps": head["steps"], "warmup": a.warmup, "ms_per_step": 1e3 * head["step_s"],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": a.dtype,
             "data": "synthetic",
-            "config": {"workload": f"{a.res}, 16 frames, 50-step DDIM schedule (eta 1.0, uniform_trailing), "
-                                   f"cfg 4.0 => 2 U-Net forwards/step, 1.44 B-parameter U-Net (BASELINE configs[1] at 320x512)",
-                       "latent": [T, h, w], "parallelism": mode},
-            "sec_per_2s_video": 50.0 * elapsed / a.steps,
+            "config": {"workload": f"{res} (latent {T}x{head['latent'][1]}x{head['latent'][2]}), 16 frames, 50-step DDIM "
+                                   f"schedule (eta 1.0, uniform_trailing), cfg 4.0 => 2 U-Net forwards/step, 1.44 B-parameter "
+                                   f"U-Net = BASELINE configs[{1 if res == '320x512' else 2}]; the same run also measures "
+                                   f"{'576x1024 (configs[2]) -> res_576x1024' if only is None else 'only this resolution'}",
+                       "latent": head["latent"], "parallelism": mode},
+            "sec_per_2s_video": 50.0 * head["step_s"],
             "ae_decode_ms_16_frames": decode_ms,
-            "sec_per_2s_video_incl_decode": None if decode_ms is None else 50.0 * elapsed / a.steps + 1e-3 * decode_ms,
-            "whole_step_mfma_frac": FLOP_PER_STEP[a.res] / (elapsed / a.steps) / 1e12 / MFMA_PEAK_TFLOPS / world,
-            "roofline": {"bound": "mfma", "kernel": "pm_conv2d_3x3 (gemm_ring_kernel<A_CONV3X3_FAST>; gemm_kernel for the f32-operand and strided/upsampling convs)",
-                         "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-                         "traffic": traffic, "launches": n, "avg_launch_ms": ms / n,
-                         "share_of_step_time": (ms * 1e-3 / 2.0) / (elapsed / a.steps)},
+            "sec_per_2s_video_incl_decode": None if decode_ms is None else 50.0 * head["step_s"] + 1e-3 * decode_ms,
+            "whole_step_mfma_frac": FLOP_PER_STEP[res] / head["step_s"] / 1e12 / MFMA_PEAK_TFLOPS / world,
+            "roofline": roof(head),
         }
+        r2 = results.get("576x1024")
+        if r2 is not None and r2 is not head:
+            out["res_576x1024"] = {
+                "steps_per_s": 1.0 / r2["step_s"], "ms_per_step": 1e3 * r2["step_s"], "steps": r2["steps"],
+                "sec_per_2s_video": 50.0 * r2["step_s"], "latent": r2["latent"],
+                "whole_step_mfma_frac": FLOP_PER_STEP["576x1024"] / r2["step_s"] / 1e12 / MFMA_PEAK_TFLOPS / world,
+                "roofline": roof(r2)}
+        if r2 is not None and r2["attn_big"]["launches"]:
+            b = r2["attn_big"]
+            ach = b["flops"] / (b["ms"] * 1e-3) / 1e12
+            out["roofline_attention"] = {
+                "bound": "mfma", "kernel": "pm_attention: spatial self-attention, N = 9216 tokens x 16 frames x 5 heads x "
+                                           "head dim 64 (576x1024, U-Net level 0), attn_self_kernel",
+                "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+                "traffic": None, "launches": b["launches"], "avg_launch_ms": b["ms"] / b["launches"],
+                "flops_per_launch": b["flops"] / b["launches"]}
         if a.cpu_baseline == "auto" and world == 1:
-            out["cpu_baseline"] = cpu_baseline(pm, a.res, ins, {"c_crossattn": [ins["c_crossattn"]]})
+            out["cpu_baseline"] = cpu_baseline(unet, res, head["ins"])
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -298,12 +298,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 //     (S'(0) | max(0) | S'(1) || exp(0) | max(1) | PV(0) || exp(1) | PV(1)), so one block's VALU work sits
 //     beside the other block's MFMAs inside one wave, on top of the overlap between the two waves of a SIMD.
 constexpr float STALE_THR = 6.0f;
+constexpr float STALE_SUM = 1024.0f;
 
-template <typename T, int QB, bool PIPE>
-__global__ __launch_bounds__(256, 2) void attn_self_kernel(const AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE_BYTES];  // K[2], V[2]
+template <typename T, int QB, bool PIPE, bool POST, int RING>
+__global__ __launch_bounds__(256, (QB == 1 && RING == 2) ? 3 : 2) void attn_self_kernel(const AttnParams p) {
+  constexpr bool NOBAR = false;
+  __shared__ __attribute__((aligned(16))) char smem[2 * RING * KV_TILE_BYTES];  // K[RING], V[RING]
   char* const Ks = smem;
-  char* const Vs = smem + 2 * KV_TILE_BYTES;
+  char* const Vs = smem + RING * KV_TILE_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, hh = lane >> 5;
@@ -403,8 +405,9 @@ __global__ __launch_bounds__(256, 2) void attn_self_kernel(const AttnParams p) {
   };
 
   // one K/V tile.  CAREFUL: exact maximum + key masking (first tile, ragged last tile).
-  auto tile = [&](int kt, int buf, auto careful_c) {
+  auto tile = [&](int kt, auto bufc, auto careful_c) {
     constexpr bool CAREFUL = decltype(careful_c)::value;
+    const int buf = bufc;  // (an integral_constant in the fast loop: LDS offsets fold into the reads' immediates)
     const char* ks = Ks + buf * KV_TILE_BYTES;
     const char* vs = Vs + buf * KV_TILE_BYTES;
     Pack8<T> pf[QB][4];
@@ -455,26 +458,46 @@ __global__ __launch_bounds__(256, 2) void attn_self_kernel(const AttnParams p) {
             }
         }
       }
-      // ---- this lane's maximum over its 32 scores of the tile ----
-      float m0 = fmaxf(sacc[0][0], sacc[1][0]);
+      // this lane's maximum over its 32 scores of the tile
+      auto lane_max = [&]() -> float {
+        float m0 = fmaxf(sacc[0][0], sacc[1][0]);
 #pragma unroll
-      for (int r = 1; r < 16; ++r) m0 = fmaxf(fmaxf(m0, sacc[0][r]), sacc[1][r]);
+        for (int r = 1; r < 16; ++r) m0 = fmaxf(fmaxf(m0, sacc[0][r]), sacc[1][r]);
+        return m0;
+      };
+      // p = 2^S', 16-bit P operand; returns this lane's sum of p
+      auto softmax = [&]() -> float {
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float pe = __builtin_amdgcn_exp2f(sacc[kb][r]);
+            ps[r & 3] += pe;
+            pf[qb][kb * 2 + (r >> 3)].e[r & 7] = from_f32<T>(pe);
+          }
+        return (ps[0] + ps[1]) + (ps[2] + ps[3]);
+      };
+      float psum;
       if constexpr (CAREFUL) {
-        raise(qb, sacc, m0, kt == 0);
-      } else {
-        if (__builtin_amdgcn_ballot_w64(m0 > STALE_THR) != 0) raise(qb, sacc, m0, false);
-      }
-      // ---- p = 2^S', row sum, 16-bit P operand ----
-      float ps[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pe = __builtin_amdgcn_exp2f(sacc[kb][r]);
-          ps[r & 3] += pe;
-          pf[qb][kb * 2 + (r >> 3)].e[r & 7] = from_f32<T>(pe);
+        raise(qb, sacc, lane_max(), kt == 0);
+        psum = softmax();
+      } else if constexpr (POST) {
+        // no maximum at all in the steady state: exponentiate against the stale m and look at the row sum that
+        // is formed anyway - a score more than 10 above m (or an overflow: inf) shows as a lane sum > 2^10;
+        // only then the exact maximum is taken, m raised and the tile's P redone (nothing of it has been
+        // accumulated yet).  Below that bound every p <= 2^10: safe for f32 sums and the 16-bit operand.
+        psum = softmax();
+        if (__builtin_amdgcn_ballot_w64(!(psum <= STALE_SUM)) != 0) {
+          raise(qb, sacc, lane_max(), false);
+          psum = softmax();
         }
-      l_run[qb] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+      } else {
+        const float m0 = lane_max();
+        if (__builtin_amdgcn_ballot_w64(m0 > STALE_THR) != 0) raise(qb, sacc, m0, false);
+        psum = softmax();
+      }
+      l_run[qb] += psum;
       if constexpr (!PIPE) {
         pv(qb);
         __builtin_amdgcn_sched_barrier(0);  // keep the blocks apart: interleaved, their live ranges spill
@@ -483,22 +506,55 @@ __global__ __launch_bounds__(256, 2) void attn_self_kernel(const AttnParams p) {
     if constexpr (PIPE) pv(QB - 1);
   };
 
-  load_kv(0, 0);
-  __syncthreads();  // drains the DMA (vmcnt) before the barrier
+  // K/V ring: RING stages of 64 keys, the DMAs of the next RING-1 tiles in flight ACROSS the per-tile barrier
+  // (counted s_waitcnt vmcnt + raw s_barrier; a __syncthreads() would drain them: with one tile of look-ahead
+  // every tile paid the L2 / Infinity-Cache round trip, MFMA pipes 46 % busy at 2.0 GHz with the VALU diet).
+  // Tile t lives in stage t % RING.  arrive(t): this wave's share of tile t has landed (each tile is 4 DMAs
+  // per wave, younger tiles may stay in flight), then the barrier publishes everybody's share and proves that
+  // every wave is done with tile t-1, whose stage the load issued right behind it (tile t+RING-1) overwrites.
+  auto arrive = [&](int t) {
+    if constexpr (RING == 2) {  // classic double buffer: 32 KiB of LDS, three workgroups per CU at 32 rows per wave
+      __syncthreads();          // (drains this wave's DMAs, publishes tile t, frees tile t-1's stage)
+      if (t + 1 < nkt) load_kv(t + 1, (t + 1) & 1);
+    } else {
+      const int ahead = (nkt - 1 - t < RING - 2) ? nkt - 1 - t : RING - 2;  // younger tiles already issued
+      if (ahead >= 2)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (ahead == 1)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (!NOBAR) __builtin_amdgcn_s_barrier();
+      if (t + RING - 1 < nkt) load_kv(t + RING - 1, (t + RING - 1) % RING);
+    }
+  };
+  static_assert(RING == 4 || RING == 2, "the vmcnt ladder above is written for 3 tiles of look-ahead");
+#pragma unroll
+  for (int t = 0; t < RING - 1; ++t)
+    if (t < nkt) load_kv(t, t);
   // three separate loops (careful first tile | fast tiles | careful ragged tile): with the two variants as the
   // arms of one loop body hipcc copied the 16-register accumulator tuples at every merge (~50 v_mov per tile)
   const int last_full = (Nk % KV_TILE == 0) ? nkt : nkt - 1;  // tiles [1, last_full) need no masking
-  if (nkt > 1) load_kv(1, 1);
-  tile(0, 0, std::true_type{});
-  __syncthreads();
-  for (int kt = 1; kt < last_full; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nkt) load_kv(kt + 1, buf ^ 1);
-    tile(kt, buf, std::false_type{});
-    __syncthreads();
+  arrive(0);
+  tile(0, std::integral_constant<int, 0>{}, std::true_type{});
+  int kt = 1;
+  for (; kt + 3 < last_full; kt += 4) {  // four tiles per trip: every tile's stage is a compile-time constant
+    arrive(kt);
+    tile(kt, std::integral_constant<int, 1>{}, std::false_type{});
+    arrive(kt + 1);
+    tile(kt + 1, std::integral_constant<int, 2 % RING>{}, std::false_type{});
+    arrive(kt + 2);
+    tile(kt + 2, std::integral_constant<int, 3 % RING>{}, std::false_type{});
+    arrive(kt + 3);
+    tile(kt + 3, std::integral_constant<int, 0 % RING>{}, std::false_type{});
+  }
+  for (; kt < last_full; ++kt) {
+    arrive(kt);
+    tile(kt, kt % RING, std::false_type{});
   }
   if (nkt > 1 && last_full < nkt) {
-    tile(nkt - 1, (nkt - 1) & 1, std::true_type{});
+    arrive(nkt - 1);
+    tile(nkt - 1, (nkt - 1) % RING, std::true_type{});
   }
 
 #pragma unroll
@@ -669,28 +725,30 @@ extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const voi
                       hipLaunchKernelGGL((attn_kernel<T, 1, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
                       return check_launch());
   }
-  // single segment.  64 query rows per wave (256 per workgroup) whenever that still gives every CU its two
-  // workgroups; 32 rows per wave below that (short sequences: finer tail)
+  // single segment: 32 query rows per wave (128 per workgroup), double-buffered K/V, three workgroups per CU.
+  // Measured on the U-Net's shapes (tools/attn_bench.py, interleaved A/B in one process, random data): this is
+  // the fastest at every N (1020-1035 TF/s at N = 9216).  The 64-rows-per-wave forms (variants 3 / 5: half the
+  // LDS fragment reads per MFMA, a 4-stage K/V ring, 2.0 GHz instead of 1.75) lose 1-3 % there and more on
+  // short sequences; kept for A/B runs.
   const int variant = g_attn_variant;
-  const bool qb2 = variant == 2 || variant == 3 || (variant == 0 && ((Nq + 255) / 256) * B * heads >= 512);
+  const bool qb2 = variant == 3 || variant == 5;
   const int rows = qb2 ? 256 : 128;
   p.nqt = (int)((Nq + rows - 1) / rows);
   dim3 grid((unsigned)(p.nqt * B * heads));
+#define PM_ATTN_LAUNCH(QB_, PIPE_, POST_, RING_)                                                                   \
+  PM_DISPATCH_DTYPE(dtype, T,                                                                                      \
+                    hipLaunchKernelGGL((attn_self_kernel<T, QB_, PIPE_, POST_, RING_>), grid, dim3(256), 0,         \
+                                       (hipStream_t)stream, p);                                                    \
+                    return check_launch())
   if (variant == 9)  // (kept for A/B runs: the round-1 kernel)
     PM_DISPATCH_DTYPE(dtype, T,
                       hipLaunchKernelGGL((attn_kernel<T, 1, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
                       return check_launch());
-  if (qb2 && variant == 3)
-    PM_DISPATCH_DTYPE(dtype, T,
-                      hipLaunchKernelGGL((attn_self_kernel<T, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
-                      return check_launch());
-  if (qb2)
-    PM_DISPATCH_DTYPE(dtype, T,
-                      hipLaunchKernelGGL((attn_self_kernel<T, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
-                      return check_launch());
-  PM_DISPATCH_DTYPE(dtype, T,
-                    hipLaunchKernelGGL((attn_self_kernel<T, 1, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
-                    return check_launch());
+  if (variant == 3) PM_ATTN_LAUNCH(2, true, false, 4);
+  if (variant == 4) PM_ATTN_LAUNCH(1, false, true, 2);
+  if (variant == 5) PM_ATTN_LAUNCH(2, true, true, 4);
+  PM_ATTN_LAUNCH(1, false, false, 2);
+#undef PM_ATTN_LAUNCH
 }
 
 extern "C" int pm_attention_temporal(const void* q, int64_t ldq, const void* k, const void* v,
