@@ -43,6 +43,14 @@ extern "C" {
 #define PM_FLAG_A_F32 1   /* the A operand (activations) is f32; rounded to `dtype` while staging   */
 #define PM_FLAG_OUT_F32 2 /* C and `residual` are f32 (bias/act/residual add and the store in f32) */
 #define PM_FLAG_RES_F32 4 /* `residual` is f32 while C stays 16-bit (last add of a block's stream)  */
+#define PM_FLAG_A_LO 16 /* pm_gemm with PM_FLAG_A_F32: stage  a - round(a)  (the low part the plain pass drops).  A
+                        * GEMM whose A operand IS the f32 residual stream (the 1x1 skip_connection of a ResBlock
+                        * that changes width, openaimodel3d.py:185-190) puts the whole stream through one 16-bit
+                        * rounding; two passes - plain, then PM_FLAG_A_LO accumulating onto the first result
+                        * (residual = C, in place) - carry it at ~2x the mantissa instead */
+#define PM_FLAG_BIAS_IS_SCALE 8 /* pm_gemm: `bias[n]` MULTIPLIES column n (in f32, before the one rounding of the
+                                 * store) instead of adding: the softmax scale on the q third of a fused q|k|v
+                                 * projection (attention.py:103 `* self.scale`), at no extra rounding */
 
 /* activation fused into a GEMM / conv epilogue */
 #define PM_ACT_NONE 0
@@ -59,7 +67,8 @@ int pm_abi_version(void);
  * :269,290,302,306 (proj_in/out), :336,362,374,405, :418-442 (GEGLU feed-forward),
  * openaimodel3d.py:185-190 (1x1 skip_connection).
  *   epilogue: + bias[n] (f32, may be NULL) -> act -> + residual[m, n] (may be NULL) -> store.
- *   flags: PM_FLAG_A_F32 (lda % 4 == 0), PM_FLAG_OUT_F32 (not with GEGLU).
+ *   flags: PM_FLAG_A_F32 (lda % 4 == 0), PM_FLAG_OUT_F32 (not with GEGLU), PM_FLAG_BIAS_IS_SCALE (bias != NULL,
+ *     not with GEGLU: epilogue = * bias[n] -> act -> + residual).
  *   PM_ACT_GEGLU: W holds 2*Nout rows interleaved [16 value rows | 16 gate rows] per 32-row group,
  *     bias likewise; C is [M, Nout] with Nout = N/2:  C = (v + bv) * gelu_erf(g + bg).
  *   requirements: K % 64 == 0, lda/ldw % 8 == 0, 16-byte aligned bases; any M, N >= 1.

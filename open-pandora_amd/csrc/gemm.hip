@@ -31,6 +31,8 @@ struct GemmParams {
   int M, N, K;
   int act;
   int out32, res32;  // f32 output / f32 residual (independent)
+  int a_lo;          // PM_FLAG_A_LO (f32 A only): stage a - round16(a), the part the plain pass rounds away
+  int bias_mul;      // PM_FLAG_BIAS_IS_SCALE: `bias` multiplies the accumulator (per-column scale) instead of adding
   int ntiles, mtiles;
   int splits, ktps;  // split-K: number of K slices and K-tiles per slice
   float* ws;         // split-K partial slabs [splits][M][N] f32
@@ -185,7 +187,7 @@ __device__ __forceinline__ void store_fast(const GemmParams& p, f32x4 (&acc)[4][
 template <typename T>
 __device__ __forceinline__ bool residual_into_acc(const GemmParams& p, f32x4 (&acc)[4][4], int m0, int n0, int wm,
                                                   int wn, int fr, int fq) {
-  if (p.R == nullptr || p.splits > 1 || p.act != PM_ACT_NONE || (p.N & 7) || (p.ldc & 7) || (p.ldr & 7)) return false;
+  if (p.R == nullptr || p.splits > 1 || p.act != PM_ACT_NONE || p.bias_mul || (p.N & 7) || (p.ldc & 7) || (p.ldr & 7)) return false;
   const bool f32res = p.res32 != 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -237,12 +239,21 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, f32x4 (&acc)[
   // ---- fast flavours (every shape of the U-Net except N % 8 != 0, i.e. the 4-channel output conv) ----
   if (FAST && !geglu && (nout & 7) == 0 && (ldc & 7) == 0 && (p.R == nullptr || (p.ldr & 7) == 0)) {
     // bias and activation in place (one uniform branch per activation, not per element group)
+    if (p.bias_mul && !partial) {  // (uniform) per-column scale, e.g. the softmax scale on the q third of a q|k|v projection
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] += bv[j][r];
+          for (int r = 0; r < 4; ++r) acc[i][j][r] *= bv[j][r];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] += bv[j][r];
+    }
     if (act == PM_ACT_SILU) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -361,8 +372,9 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, f32x4 (&acc)[
           float v[8];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            v[r] = acc[i][2 * jp][r] + bv[2 * jp][r];
-            v[4 + r] = acc[i][2 * jp + 1][r] + bv[2 * jp + 1][r];
+            v[r] = (p.bias_mul && !partial) ? acc[i][2 * jp][r] * bv[2 * jp][r] : acc[i][2 * jp][r] + bv[2 * jp][r];
+            v[4 + r] = (p.bias_mul && !partial) ? acc[i][2 * jp + 1][r] * bv[2 * jp + 1][r]
+                                                : acc[i][2 * jp + 1][r] + bv[2 * jp + 1][r];
           }
           if (act == PM_ACT_SILU) {
 #pragma unroll
@@ -705,6 +717,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
       for (int e = 0; e < 4; ++e) {
         cv.e[e] = from_f32<T>(lo.f[e]);
         cv.e[e + 4] = from_f32<T>(hi.f[e]);
+      }
+      if (p.a_lo) {  // (uniform) second pass of a split-operand call: what the first pass rounded away
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          cv.e[e] = from_f32<T>(lo.f[e] - to_f32(cv.e[e]));
+          cv.e[e + 4] = from_f32<T>(hi.f[e] - to_f32(cv.e[e + 4]));
+        }
       }
       *reinterpret_cast<u32x4*>(As + off) = cv.u;
       *reinterpret_cast<u32x4*>(Bs + off) = rb[j];
@@ -1192,7 +1211,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
       }
     }
     for (int e = 0; e < 4 && n + e < p.N; ++e) {
-      float x = v[e] + (p.bias ? p.bias[n + e] : 0.f);
+      float x = p.bias_mul ? v[e] * p.bias[n + e] : v[e] + (p.bias ? p.bias[n + e] : 0.f);
       if (p.act == PM_ACT_SILU) x = silu_f(x);
       if (p.act == PM_ACT_GELU) x = gelu_erf_f(x);
       if (p.R) x += p.res32 ? reinterpret_cast<const float*>(p.R)[m * p.ldr + n + e]
@@ -1247,7 +1266,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const GemmPara
       const int m = r0 + rl + 4 * u;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float x = v[u][e] + bias4[e];
+        float x = p.bias_mul ? v[u][e] * bias4[e] : v[u][e] + bias4[e];
         if (p.act == PM_ACT_SILU) x = silu_f(x);
         if (p.act == PM_ACT_GELU) x = gelu_erf_f(x);
         v[u][e] = x;
@@ -1456,11 +1475,15 @@ extern "C" int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, c
   if ((lda & ((flags & PM_FLAG_A_F32) ? 3 : 7)) || (ldw & 7) || lda < K || ldw < K) return PM_E_SHAPE;
   if (!fits_u32(M * lda, flags) || N * ldw * 2 >= (1ll << 32)) return PM_E_SHAPE;  // 32-bit lane offsets
   if ((flags & PM_FLAG_OUT_F32) && act == PM_ACT_GEGLU) return PM_E_SHAPE;
+  if ((flags & PM_FLAG_BIAS_IS_SCALE) && (bias == nullptr || act == PM_ACT_GEGLU)) return PM_E_SHAPE;
+  if ((flags & PM_FLAG_A_LO) && !(flags & PM_FLAG_A_F32)) return PM_E_SHAPE;
   GemmParams p{};
   p.A = A; p.lda = lda; p.Wt = W; p.ldw = ldw; p.bias = bias; p.R = residual; p.ldr = ldr;
   p.C = C; p.ldc = ldc; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
   p.out32 = (flags & PM_FLAG_OUT_F32) ? 1 : 0;
   p.res32 = (flags & (PM_FLAG_OUT_F32 | PM_FLAG_RES_F32)) ? 1 : 0;
+  p.bias_mul = (flags & PM_FLAG_BIAS_IS_SCALE) ? 1 : 0;
+  p.a_lo = (flags & PM_FLAG_A_LO) ? 1 : 0;
   p.colstats = colstats;
   p.ntiles = (int)((N + BN - 1) / BN);
   p.zero = A;  // dense K tails never occur (K % 8 == 0 and whole chunks only); see kin below

@@ -6,6 +6,7 @@ current stream.  Activations are channels-last token matrices [frames*H*W, C] in
 There is deliberately no CPU / eager fallback here.
 """
 import math
+import os
 
 import torch
 
@@ -31,6 +32,8 @@ class HipOps:
         if dtype not in _DT:
             raise ValueError(f"HipOps supports float16/bfloat16 activations, got {dtype}")
         self.lib = capi.load()
+        if os.environ.get("PANDORA_Q_PRESCALE", "1") == "0":  # (numerics experiments: scale inside the kernel)
+            self.q_prescale = None
         self.dtype = dtype
         self.dt = _DT[dtype]
         self.device = torch.device(device)
@@ -108,13 +111,22 @@ class HipOps:
         return out, tot
 
     # -- GEMM family -----------------------------------------------------------------------------
-    def gemm(self, a, w, bias=None, residual=None, act="none", out=None, stream=False, stats=None):
-        """out[M, N] = epi(a[M, K] @ w[N, K]^T); GEGLU halves N (weights pre-interleaved)."""
+    def gemm(self, a, w, bias=None, residual=None, act="none", out=None, stream=False, stats=None, col_scale=None,
+             split_a=False):
+        """out[M, N] = epi(a[M, K] @ w[N, K]^T); GEGLU halves N (weights pre-interleaved).
+        col_scale f32 [N] (instead of a bias): column n is multiplied by col_scale[n] in f32 before the store.
+        split_a (f32 `a`, stream output): two passes, a = hi + lo in 16 bit each (PM_FLAG_A_LO)."""
+        if split_a and a.dtype == torch.float32 and stream and act == "none":
+            y = self.gemm(a, w, bias, residual, out=out, stream=True)
+            return self._gemm_lo(a, w, y, stats)
         M, K = a.shape
         N = w.shape[0]
         assert w.shape[1] == K and w.is_contiguous() and w.dtype == self.dtype
         n_out = N // 2 if act == "geglu" else N
         flags, out = self._gemm_io(a, residual, out, M, n_out, stream)
+        if col_scale is not None:
+            assert bias is None and col_scale.dtype == torch.float32 and col_scale.numel() == N
+            bias, flags = col_scale, flags | capi.PM_FLAG_BIAS_IS_SCALE
         col = self._stats_begin(M, n_out, stats, K)
         rc = self.lib.pm_gemm(_ptr(a), self._rows(a, True), _ptr(w), K, _ptr(bias),
                               _ptr(residual), residual.stride(0) if residual is not None else 0,
@@ -122,6 +134,18 @@ class HipOps:
                               _ptr(self.workspace), self.ws_bytes, _ptr(col[0] if col else None), self._stream())
         capi.check(rc, f"pm_gemm M={M} N={N} K={K}")
         return self._stats_end(out, col, stats)
+
+    def _gemm_lo(self, a, w, y, stats):
+        """y += (a - round16(a)) @ w^T, in place (y f32); fused statistics, if wanted, come from this final pass."""
+        M, K = a.shape
+        N = w.shape[0]
+        col = self._stats_begin(M, N, stats, K)
+        flags = capi.PM_FLAG_A_F32 | capi.PM_FLAG_OUT_F32 | capi.PM_FLAG_A_LO
+        rc = self.lib.pm_gemm(_ptr(a), self._rows(a, True), _ptr(w), K, 0, _ptr(y), y.stride(0), _ptr(y), y.stride(0),
+                              M, N, K, capi.PM_ACT_NONE, flags, self.dt, _ptr(self.workspace), self.ws_bytes,
+                              _ptr(col[0] if col else None), self._stream())
+        capi.check(rc, f"pm_gemm (low part) M={M} N={N} K={K}")
+        return self._stats_end(y, col, stats)
 
     def conv3x3(self, x, wp, bias, F, H, W, stride=1, upsample=False, residual=None, out=None, stream=False,
                 pad_lo=1, stats=None):

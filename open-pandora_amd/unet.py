@@ -288,6 +288,8 @@ class UNetModel(nn.Module):
         wt = lambda t: t.detach().to(device=dev, dtype=dt).contiguous()
         f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
 
+        inner_of = lambda attn: attn.to_q.weight.shape[0]
+
         def lin(mod):
             w = mod.weight
             if w.dim() > 2:  # 1x1 Conv1d / Conv2d
@@ -321,14 +323,13 @@ class UNetModel(nn.Module):
                 for i, ln in enumerate((blk.norm1, blk.norm2, blk.norm3), 1):
                     e[f"ln{i}"] = (f32(ln.weight), f32(ln.bias))
                 a1 = blk.attn1
-                wq = a1.to_q.weight
-                # spatial self-attention: the softmax scale (and the base-2 conversion) ride on the q projection,
-                # folded into its weights in f32 before the one rounding to the kernel dtype (ops.q_prescale)
+                # spatial self-attention: the softmax scale (and the base-2 conversion) ride on the q third of the
+                # fused projection as a per-column scale of its epilogue (f32, before the one rounding: exact)
                 pre = getattr(ops, "q_prescale", None) if isinstance(mod, SpatialTransformer) else None
                 if pre is not None:
-                    wq = wq.detach().float() * pre
-                    e["a1_prescaled"] = True
-                e["a1_qkv"] = wt(torch.cat([wq, a1.to_k.weight.detach().float(), a1.to_v.weight.detach().float()], 0))
+                    e["a1_qscale"] = torch.cat([torch.full((inner_of(a1),), float(pre)), torch.ones(2 * inner_of(a1))]
+                                               ).to(device=dev, dtype=torch.float32)
+                e["a1_qkv"] = wt(torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0))
                 e["a1_out"] = lin(a1.to_out[0])
                 a2 = blk.attn2
                 if a2.self_attn:
@@ -411,7 +412,9 @@ class UNetModel(nn.Module):
         # every conv whose output feeds a GroupNorm also emits that norm's statistics from its epilogue
         h, tot = ops.conv3x3(h, e["conv1"], c.emb_bias[lo:hi], c.F, c.H, c.W, stream=True, stats=(c.F, 32))
         h = self._gn(c, h, e["gn2"], 1e-5, True, True, totals=tot)
-        skip = x if e["skip"] is None else ops.gemm(x, e["skip"][0], e["skip"][1], stream=True)
+        # the 1x1 skip conv puts the WHOLE stream through a 16-bit operand: carried as hi + lo (two passes), its
+        # rounding was 10 % of the end-to-end error (tests/test_error_budget_gpu.py)
+        skip = x if e["skip"] is None else ops.gemm(x, e["skip"][0], e["skip"][1], stream=True, split_a=True)
         if not mod.use_temporal_conv:
             return self._keep_stats(c, ops.conv3x3(h, e["conv2"][0], e["conv2"][1], c.F, c.H, c.W, residual=skip,
                                                    stream=True, stats=self._stream_stats(c), out=out))
@@ -439,13 +442,14 @@ class UNetModel(nn.Module):
             y = ops.layernorm(h, *e[f"ln{which}"])
             key = f"a{which}_qkv"
             if key in e:  # self-attention, fused q|k|v projection
-                qkv = v3(ops.gemm(y, e[key]), 3 * inner)
+                qs = e.get("a1_qscale") if which == 1 else None
+                qkv = v3(ops.gemm(y, e[key]) if qs is None else ops.gemm(y, e[key], col_scale=qs), 3 * inner)
                 q, k, v = qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:]
                 if temporal:
                     if gather:  # frame-sharded without the pixel re-shard: all-gather K|V over frames
                         k, v = c.fp.gather_kv(qkv, inner, P)
                     a = ops.attention_temporal(q, k, v, heads)
-                elif which == 1 and e.get("a1_prescaled", False):
+                elif qs is not None:
                     a = ops.attention(q, k, v, heads, prescaled=True)
                 else:
                     a = ops.attention(q, k, v, heads)

@@ -257,8 +257,47 @@ def gen_oracle_72x128():
     save("unet_full_72x128_oracle.npz", **out)
 
 
+def gen_full_72x128(traj_steps=0):
+    """576x1024 (16x72x128 latent, 9216 spatial tokens at level 0) through the REAL reference: one conditional
+    forward, or a short CFG-4 eta-0 DDIM trajectory.  The reference's attention is called frame by frame
+    (rh.chunk_attention_over_frames: a memory shim, same arithmetic)."""
+    torch.set_num_threads(os.cpu_count() or 8)
+    t0 = time.time()
+    m = rh.reference_diffusion(base_scale=0.3)
+    unet = m.model.diffusion_model
+    unet.load_state_dict(synth.synth_state_dict(unet, seed=WEIGHT_SEED))
+    rh.chunk_attention_over_frames(unet)
+    print(f"full model ready in {time.time() - t0:.0f}s", flush=True)
+    h, w = 72, 128
+    ins, cond, uc = _small_setup(320, h, w)
+    out = {"source": np.array("the real reference (lvdm UNetModel / DDIMSampler), attention called per frame")}
+    if not traj_steps:
+        t0 = time.time()
+        with torch.no_grad():
+            y = m.apply_model(ins["x_T"], torch.tensor([500]), cond, fs=torch.tensor([15]))
+        print(f"reference forward 72x128 cond: {time.time() - t0:.0f}s std {y.std():.4f}", flush=True)
+        for k, v in digest(y, n=8192).items():
+            out[f"cond/{k}"] = v
+        save("unet_full_72x128.npz", **out)
+    else:
+        t0 = time.time()
+        smp = rh.reference_sampler(m)
+        y, _ = smp.sample(S=traj_steps, batch_size=1, shape=(4, 16, h, w), conditioning=cond, verbose=True,
+                          unconditional_guidance_scale=4.0, unconditional_conditioning=uc, eta=0.0,
+                          fs=torch.tensor([15]), timestep_spacing="uniform_trailing", x_T=ins["x_T"])
+        dt = time.time() - t0
+        print(f"{traj_steps}-step trajectory 72x128: {dt:.0f}s", flush=True)
+        for k, v in digest(y, n=8192).items():
+            out[f"sample/{k}"] = v
+        out["wall_seconds"] = np.float64(dt)
+        out["threads"] = np.int64(torch.get_num_threads())
+        save(f"ddim_full_72x128_s{traj_steps}.npz", **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
+    ap.add_argument("--full-72x128", action="store_true")
+    ap.add_argument("--traj-72x128", type=int, default=0)
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--traj", action="store_true")
     ap.add_argument("--oracle-72x128", action="store_true")
@@ -266,6 +305,10 @@ if __name__ == "__main__":
     ap.add_argument("--rescale", action="store_true")
     ap.add_argument("--resampler", action="store_true")
     a = ap.parse_args()
+    if a.full_72x128 or a.traj_72x128:
+        assert rh.available()
+        gen_full_72x128(a.traj_72x128)
+        sys.exit(0)
     if a.resampler:
         assert rh.available()
         gen_resampler()

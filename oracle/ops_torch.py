@@ -26,9 +26,16 @@ def _f(t):
 class TorchOps:
     name = "torch-oracle"
 
-    def __init__(self, dtype=torch.float32, device="cpu"):
+    def __init__(self, dtype=torch.float32, device="cpu", model_16bit=False):
+        """model_16bit (with a 16-bit dtype): the IDEAL 16-bit-operand machine - exact f32 arithmetic, but
+        every tensor the HIP path stores as 16 bit (the MFMA operands: normalised activations, q/k/v, the
+        attention probabilities P, attention outputs, GEGLU products) is rounded to `dtype`, and what it keeps
+        in f32 (`stream=True` outputs: the residual stream) stays f32.  Its distance from the f32 reference is
+        the error inherent to 16-bit matrix operands, independent of any kernel
+        (tests/test_error_budget_gpu.py compares the HIP kernels with it)."""
         self.dtype = dtype
         self.device = torch.device(device)
+        self.model_16bit = bool(model_16bit) and dtype != torch.float32
 
     def empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.dtype, device=self.device)
@@ -41,16 +48,29 @@ class TorchOps:
         yg = y.float().reshape(NI, y.shape[0] // NI, groups, -1)
         return y, torch.stack([yg.sum((1, 3)), (yg * yg).sum((1, 3))], -1)
 
-    def _out(self, t, out):
-        t = t.to(self.dtype)
+    def _a(self, t):
+        """A operand of a GEMM-family op: the MFMA takes it as 16 bit even when it is read from the f32 residual
+        stream (1x1 skip convs, Down/Upsample convs: PM_FLAG_A_F32 rounds while staging)."""
+        return t.to(self.dtype).float() if self.model_16bit else t.float()
+
+    def _out(self, t, out, stream=False):
+        t = t.to(torch.float32 if (stream and self.model_16bit) else self.dtype)
         if out is not None:
             out.copy_(t)
             return out
         return t
 
     # -- GEMM family -----------------------------------------------------------------------------
-    def gemm(self, a, w, bias=None, residual=None, act="none", out=None, stream=False, stats=None):
-        y = _f(a) @ _f(w).t()
+    def gemm(self, a, w, bias=None, residual=None, act="none", out=None, stream=False, stats=None, col_scale=None,
+             split_a=False):
+        if split_a and self.model_16bit and a.dtype == torch.float32:  # hi + lo: two 16-bit operands carry a
+            hi = a.to(self.dtype).float()
+            af = hi + (a - hi).to(self.dtype).float()
+        else:
+            af = self._a(a)
+        y = af @ _f(w).t()
+        if col_scale is not None:
+            y = y * _f(col_scale)
         if bias is not None:
             y = y + _f(bias)
         if act == "silu":
@@ -64,12 +84,12 @@ class TorchOps:
             y = (yy[:, :, 0] * F_.gelu(yy[:, :, 1])).reshape(y.shape[0], n // 2)
         if residual is not None:
             y = y + _f(residual)
-        return self._with_stats(self._out(y, out), stats)
+        return self._with_stats(self._out(y, out, stream), stats)
 
     def conv3x3(self, x, wp, bias, F, H, W, stride=1, upsample=False, residual=None, out=None, stream=False,
                 pad_lo=1, stats=None):
         cin, cout = x.shape[1], wp.shape[0]
-        xi = _f(x).reshape(F, H, W, cin).permute(0, 3, 1, 2)
+        xi = self._a(x).reshape(F, H, W, cin).permute(0, 3, 1, 2)
         if upsample:
             xi = F_.interpolate(xi, scale_factor=2, mode="nearest")
         w = _f(wp).reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)  # -> [Cout, Cin, ky, kx]
@@ -78,12 +98,12 @@ class TorchOps:
         y = y.permute(0, 2, 3, 1).reshape(-1, cout)
         if residual is not None:
             y = y + _f(residual)
-        return self._with_stats(self._out(y, out), stats)
+        return self._with_stats(self._out(y, out, stream), stats)
 
     def conv_t3(self, x, wp, bias, F, P, residual=None, halo_lo=None, halo_hi=None, out=None, stream=False,
                 stats=None):
         cin, cout = x.shape[1], wp.shape[0]
-        xi = _f(x).reshape(F, P, cin)
+        xi = self._a(x).reshape(F, P, cin)
         lo = torch.zeros(1, P, cin) if halo_lo is None else _f(halo_lo).reshape(1, P, cin)
         hi = torch.zeros(1, P, cin) if halo_hi is None else _f(halo_hi).reshape(1, P, cin)
         xe = torch.cat([lo, xi, hi], 0)  # frames -1 .. F
@@ -94,7 +114,7 @@ class TorchOps:
         y = y[0, :, :, :, 0].permute(1, 2, 0).reshape(F * P, cout)
         if residual is not None:
             y = y + _f(residual)
-        return self._with_stats(self._out(y, out), stats)
+        return self._with_stats(self._out(y, out, stream), stats)
 
     def gemv(self, w, x, bias=None, silu_in=False, act="none"):
         xv = _f(x)
@@ -137,8 +157,7 @@ class TorchOps:
         return self._out(F_.layer_norm(_f(x), (x.shape[1],), _f(gamma), _f(beta), eps), out)
 
     # -- attention -------------------------------------------------------------------------------
-    @staticmethod
-    def _attn(q, k, v, heads):
+    def _attn(self, q, k, v, heads):
         B, Nq, C = q.shape
         if k.shape[0] == 1 and B > 1:
             k, v = k.expand(B, -1, -1), v.expand(B, -1, -1)
@@ -147,10 +166,15 @@ class TorchOps:
         out = torch.empty_like(qh)
         for h in range(heads):  # per head to bound the score tensor
             sim = torch.einsum("bid,bjd->bij", qh[:, h], kh[:, h]) * (64 ** -0.5)
+            if self.model_16bit:  # P (unnormalised, row maximum 1) is an MFMA operand: rounded; the row sum is f32
+                pu = torch.exp(sim - sim.amax(-1, keepdim=True))
+                out[:, h] = torch.einsum("bij,bjd->bid", pu.to(self.dtype).float(), vh[:, h]) / pu.sum(-1, keepdim=True)
+                continue
             out[:, h] = torch.einsum("bij,bjd->bid", sim.softmax(dim=-1), vh[:, h])
         return out.permute(0, 2, 1, 3).reshape(B, Nq, C)
 
-    def attention(self, q, k1, v1, heads, k2=None, v2=None, w2=1.0, out=None):
+    def attention(self, q, k1, v1, heads, k2=None, v2=None, w2=1.0, out=None, prescaled=False):
+        assert not prescaled, "TorchOps has no q_prescale: callers fold nothing"
         y = self._attn(_f(q), _f(k1), _f(v1), heads)
         if k2 is not None:
             y = y + w2 * self._attn(_f(q), _f(k2), _f(v2), heads)

@@ -44,6 +44,39 @@ def test_gemm_bias_residual(hip_ops_factory, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(300, 960, 320), (640, 3840, 1280)])  # (unsplit; split-K: the scale is in the reduce)
+def test_gemm_column_scale(hip_ops_factory, dtype, M, N, K):
+    """PM_FLAG_BIAS_IS_SCALE: out[:, n] = (a @ w^T)[:, n] * s[n], scaled in f32 before the one rounding of the
+    store (the softmax scale on the q third of a fused q|k|v projection)."""
+    ops = hip_ops_factory(dtype)
+    a, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=2)
+    s = torch.cat([torch.full((N // 3,), 0.18033688), torch.ones(N - N // 3)])
+    want = (a.float() @ w.float().t()) * s
+    got = ops.gemm(a.cuda(), w.cuda(), col_scale=s.cuda())
+    assert rel_err(got, want) <= TOL[dtype]
+    # exactness: on the scaled third the result is the correctly rounded product, not a re-rounded 16-bit value
+    exact = want.to(dtype).float()
+    assert (got.float().cpu()[:, :N // 3] != exact[:, :N // 3]).float().mean().item() < 0.02
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(300, 320, 640), (640, 1280, 2560)])  # (the second splits over K)
+def test_gemm_split_f32_operand(hip_ops_factory, dtype, M, N, K):
+    """split_a: an f32 A operand carried as hi + lo 16-bit parts over two passes (PM_FLAG_A_LO) - the result
+    is the f32 product to ~1e-5 instead of the 16-bit operand's 3e-4 / 2e-3; fused statistics of the final sum."""
+    ops = hip_ops_factory(dtype)
+    a = rnd(M, K, dtype=torch.float32, scale=2.0, seed=1)
+    w, bias = rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=2), rnd(N, dtype=torch.float32, seed=3)
+    want = a @ w.float().t() + bias
+    plain = ops.gemm(a.cuda(), w.cuda(), bias.cuda(), stream=True)
+    got, tot = ops.gemm(a.cuda(), w.cuda(), bias.cuda(), stream=True, split_a=True, stats=(1, 32))
+    e_plain, e_split = rel_err(plain, want), rel_err(got, want)
+    assert got.dtype == torch.float32 and e_split <= (2e-5 if dtype == torch.float16 else 1e-4) and e_split < 0.1 * e_plain
+    ref_tot = TorchOps._with_stats(want, (1, 32))[1]
+    assert rel_err(tot, ref_tot) <= 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_exact_integers(hip_ops_factory, dtype):
     """Small-integer operands make every product and sum exact: any fragment-layout mistake
     (row/col swap, k permutation) shows up as a mismatch, not as rounding."""

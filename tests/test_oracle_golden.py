@@ -126,3 +126,11 @@ def test_ddim_guidance_rescale_against_reference(S, eta, cfg, gres):
     y, _ = ddim_ref.ddim_sample(apply, ddim_ref.schedule_tables(), ins["x_T"], cond, uc, S, eta, cfg,
                                 noises=gr.noises(ins["x_T"].shape, S), fs=torch.tensor([15]), guidance_rescale=gres)
     assert np.isfinite(g).all() and rel(y, g) < 5e-5
+
+
+def test_oracle_72x128_fixture_matches_the_real_reference():
+    """Two committed digests of the same full-width forward at 16x72x128: one from the oracle (chunked attention),
+    one from the REAL reference (eager attention called per frame, oracle/make_golden.py --full-72x128)."""
+    a, b = load("unet_full_72x128.npz"), load("unet_full_72x128_oracle.npz")
+    assert int(a["cond/stride"]) == int(b["cond/stride"])
+    assert rel(b["cond/slice"], a["cond/slice"]) < 2e-5

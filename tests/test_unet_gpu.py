@@ -2,8 +2,14 @@
 golden fixtures captured from the real reference on CPU in f32.
 
 Tolerance: norm-relative error.  f16 I/O is the parity configuration of the north-star ("within 1e-3
-relative fp16 tolerance"); bf16 is the production dtype, whose output rounding alone is 2^-9 = 2e-3,
-so it carries its own (looser) bound.  Measured values are printed and recorded in DESIGN.md."""
+relative fp16 tolerance"): FWD_TOL[f16] = 1e-3 is that contract number, asserted on every full-width
+(1.44 B-parameter) forward at both BASELINE resolutions.  bf16 (the reference's own production dtype,
+8x coarser operands) carries 8e-3.  The reduced-width models (64 / 128 base channels: fewer terms per
+dot product, less averaging) have a higher floor - the error of an IDEAL 16-bit-operand machine on the
+same graph, 1.15e-3 - 1.4e-3, computed in tests/test_error_budget_gpu.py, which also shows the kernels sit on
+it - hence FWD_TOL_REDUCED.  A CFG-4 trajectory carries the per-forward error times the guidance
+amplification (s |de_c| + (s-1) |de_u|) / |v| <= 3.5 measured on the reference's own tensors (same file;
+observed 2.2): TRAJ = forward tolerance x that bound.  Measured values are printed and recorded in DESIGN.md."""
 import os
 
 import numpy as np
@@ -19,8 +25,11 @@ from test_oracle_golden import RH_KW, load, rel
 
 pytestmark = pytest.mark.gpu
 
-FWD_TOL = {torch.float16: 2e-3, torch.bfloat16: 1.5e-2}
-TRAJ_TOL = {torch.float16: 6e-3, torch.bfloat16: 5e-2}
+FWD_TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}              # full width: the contract
+FWD_TOL_REDUCED = {torch.float16: 1.6e-3, torch.bfloat16: 1.25e-2}  # 64 / 128 base channels: 16-bit-operand floor x 1.15
+CFG_AMPLIFICATION = 3.5                                             # (s |de_c| + (s-1) |de_u|) / |v| at s = 4
+TRAJ_TOL = {k: v * CFG_AMPLIFICATION for k, v in FWD_TOL.items()}
+TRAJ_TOL_REDUCED = {k: v * CFG_AMPLIFICATION for k, v in FWD_TOL_REDUCED.items()}
 
 
 def small_model(mc, ops):
@@ -39,7 +48,7 @@ def test_unet_small_forward(hip_ops_factory, dtype, tag, mc, h, w, t, fs):
     y = m(x, torch.tensor([t]).cuda(), context=ins["c_crossattn"].cuda(), fs=torch.tensor([fs]).cuda())
     err = rel(y.cpu(), g)
     print(f"\n[parity] unet_small {tag} {dtype}: rel err {err:.2e}")
-    assert err <= FWD_TOL[dtype]
+    assert err <= FWD_TOL_REDUCED[dtype]
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -59,7 +68,7 @@ def test_ddim_small_trajectory(hip_ops_factory, dtype, S, eta, cfg):
         return
     err = rel(y.cpu(), g)
     print(f"\n[parity] ddim_small S={S} eta={eta} cfg={cfg} {dtype}: rel err {err:.2e}")
-    assert err <= TRAJ_TOL[dtype]
+    assert err <= (TRAJ_TOL_REDUCED[dtype] if cfg != 1.0 else FWD_TOL_REDUCED[dtype])
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -76,7 +85,7 @@ def test_ddim_guidance_rescale_trajectory(hip_ops_factory, dtype, S, eta, cfg, g
                                   x_T=ins["x_T"].cuda(), noise_fn=lambda i, shape: ns[i], guidance_rescale=gres)
     err = rel(y.cpu(), g)
     print(f"\n[parity] ddim guidance_rescale S={S} eta={eta} cfg={cfg} gr={gres} {dtype}: rel err {err:.2e}")
-    assert err <= TRAJ_TOL[dtype]
+    assert err <= TRAJ_TOL_REDUCED[dtype]
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -143,13 +152,10 @@ def test_ddim_full_width_10_steps_40x64(hip_ops_factory, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_unet_full_width_forward_72x128(hip_ops_factory, dtype):
-    """BASELINE configs 3-5 shape: 16 x 72 x 128 latent (9216 spatial tokens at level 0).  The
-    reference's eager attention cannot run this size on the build container's CPU (27 GB of scores per
-    block), so the fixture comes from the oracle (chunked attention), which every other fixture pins."""
-    path = os.path.join(os.path.dirname(__file__), "golden", "unet_full_72x128_oracle.npz")
-    if not os.path.exists(path):
-        pytest.skip("72x128 oracle fixture not generated")
-    g = np.load(path)
+    """BASELINE configs 3-5 shape: 16 x 72 x 128 latent (9216 spatial tokens at level 0) against the REAL
+    reference's f32 CPU output (its eager attention called frame by frame by the harness: same arithmetic, 1/16
+    of the 27 GB score tensor; oracle/make_golden.py --full-72x128)."""
+    g = load("unet_full_72x128.npz")
     ops = hip_ops_factory(dtype)
     pm = factory.build_diffusion("576x1024", ops, seed=gr.WEIGHT_SEED)
     ins, cond, _ = gr.sampler_inputs(72, 128)
@@ -158,6 +164,26 @@ def test_unet_full_width_forward_72x128(hip_ops_factory, dtype):
     err, std, gstd = _digest_err(y, g, "cond")
     print(f"\n[parity] unet_full 72x128 cond {dtype}: rel err {err:.2e} (std {std:.4f} vs {gstd:.4f})")
     assert err <= FWD_TOL[dtype]
+    del pm
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16])
+def test_ddim_full_width_2_steps_72x128(hip_ops_factory, dtype):
+    """A short CFG-4 trajectory at 576x1024 (2 DDIM steps = 4 full-width forwards, eta 0) vs the real reference's
+    DDIMSampler + LatentVisualDiffusion run on CPU (oracle/make_golden.py --traj-72x128 2)."""
+    g = load("ddim_full_72x128_s2.npz")
+    ops = hip_ops_factory(dtype)
+    pm = factory.build_diffusion("576x1024", ops, seed=gr.WEIGHT_SEED)
+    ins, cond, uc = gr.sampler_inputs(72, 128)
+    dev = lambda c: {k: [t.cuda() for t in v] for k, v in c.items()}
+    y, _ = DDIMSampler(pm).sample(S=2, batch_size=1, shape=(4, 16, 72, 128), conditioning=dev(cond), verbose=False,
+                                  unconditional_guidance_scale=4.0, unconditional_conditioning=dev(uc), eta=0.0,
+                                  fs=torch.tensor([15]).cuda(), timestep_spacing="uniform_trailing",
+                                  x_T=ins["x_T"].cuda())
+    err, std, gstd = _digest_err(y, g, "sample")
+    print(f"\n[parity] ddim_full 72x128 S=2 {dtype}: rel err {err:.2e} (std {std:.4f} vs {gstd:.4f})")
+    assert err <= TRAJ_TOL[dtype]
     del pm
     torch.cuda.empty_cache()
 
@@ -173,13 +199,13 @@ def test_ae_decode_small_gpu(hip_ops_factory, dtype):
         y = ae.bind(hip_ops_factory(dtype)).decode_first_stage(gr.ae_latent(T, h, w).cuda())
         err = rel(y.cpu(), g[tag])
         print(f"\n[parity] ae_decode {tag} {dtype}: rel err {err:.2e}")
-        assert err <= FWD_TOL[dtype]
+        assert err <= FWD_TOL_REDUCED[dtype]
         if ch < 64:  # the encoder's first 1x1 shortcut has K = ch: pm_gemm needs K % 64 == 0 (full width: 128)
             continue
         mom = ae.encode_moments(gr.ae_pixels(T, 8 * h, 8 * w).cuda())
         err = rel(mom.cpu(), g["enc/" + tag])
         print(f"\n[parity] ae_encode moments {tag} {dtype}: rel err {err:.2e}")
-        assert err <= FWD_TOL[dtype]
+        assert err <= FWD_TOL_REDUCED[dtype]
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
