@@ -15,7 +15,9 @@
  *     biases and the DDIM latent are f32;
  *   - no allocation, no synchronisation, no exceptions: work is enqueued on `stream`
  *     (a hipStream_t passed as void*) and the call returns PM_OK (0) or a negative PM_E* code;
- *   - re-entrant: no global mutable state.
+ *   - re-entrant: no mutable state between calls.  (Write-once process state only: per-device launch attributes
+ *     and the CU count cached on first use, and the PANDORA_* tuning overrides - kernel choice / split-K threshold,
+ *     never results - read from the environment once, before the first sizing query or launch.)
  */
 #ifndef PANDORA_MI355X_H
 #define PANDORA_MI355X_H

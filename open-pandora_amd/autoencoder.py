@@ -105,7 +105,7 @@ DDCONFIG = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_
                 ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)  # inference yaml :57-76
 
 
-class AutoencoderKL(nn.Module):
+class AutoencoderKL(packing.PackedWeights, nn.Module):
     def __init__(self, ddconfig=None, lossconfig=None, embed_dim=4, scale_factor=0.18215, **ignored):
         super().__init__()
         dd = dict(ddconfig or DDCONFIG)
@@ -115,24 +115,20 @@ class AutoencoderKL(nn.Module):
         self.quant_conv = nn.Conv2d(2 * dd["z_channels"], 2 * embed_dim, 1)
         self.post_quant_conv = nn.Conv2d(embed_dim, dd["z_channels"], 1)
         self.embed_dim, self.scale_factor = embed_dim, scale_factor
-        self.ops, self._packed = None, None
+        self.ops = None
+        self._init_packed()
 
     def bind(self, ops):
-        self.ops, self._packed = ops, None
+        self.ops = ops
+        self.invalidate_packed()
         return self
-
-    def load_state_dict(self, *a, **k):
-        self._packed = None
-        return super().load_state_dict(*a, **k)
 
     @torch.no_grad()
     def encode_moments(self, x):
         """x (n, 3, H, W) pixels in [-1, 1] -> posterior moments (n, 8, H/8, W/8) f32 [mean | logvar]."""
         if self.ops is None:
             raise RuntimeError("AutoencoderKL.bind(ops) must be called first (no implicit CPU fallback)")
-        if self._packed is None:
-            self.prepare()
-        ops, W = self.ops, self._packed
+        ops, W = self.ops, self.packed()
         n, c, H, Wd = x.shape
         xs = x.to(device=ops.device, dtype=torch.float32).permute(1, 0, 2, 3).reshape(c, n, H * Wd).contiguous()
         pad = torch.zeros(8 - c, n, H * Wd, dtype=torch.float32, device=ops.device)
@@ -248,9 +244,7 @@ class AutoencoderKL(nn.Module):
         """z (n, 4, h, w) latents (already divided by scale_factor unless scaled=True) -> (n, 3, 8h, 8w)."""
         if self.ops is None:
             raise RuntimeError("AutoencoderKL.bind(ops) must be called first (no implicit CPU fallback)")
-        if self._packed is None:
-            self.prepare()
-        ops, W = self.ops, self._packed
+        ops, W = self.ops, self.packed()
         n, c, hh, ww = z.shape
         # the kernels address one operand with 32-bit byte offsets: keep the largest activation
         # (f32, 128 channels at full pixel resolution) under 2 GiB by decoding a few frames at a time

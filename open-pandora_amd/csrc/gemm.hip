@@ -1314,15 +1314,40 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const GemmPara
   }
 }
 
+// Process-level state of this file, all of it write-once: three environment overrides read by init_once() before
+// their first use (from EVERY entry point that depends on them, so a sizing query and the launch it sizes agree),
+// and per-DEVICE caches (CU count, "dynamic LDS limit raised" per kernel instantiation - the attribute is per
+// device, a process may drive several GPUs).
+constexpr int MAX_DEVICES = 64;
 static int g_ring = 1;  // PANDORA_GEMM_RING: 0 = never, 1 = by prefer_ring(), 2 = always
 static int g_ring_max_work = 0;  // PANDORA_GEMM_RING_MAX_WORK > 0: never use the ring kernel above that many work items
-static int g_num_cus = 0;
+static int g_num_cus[MAX_DEVICES] = {0};
+static int g_split_min_nk = 24;     // PANDORA_SPLITK_MIN_NK: shortest K loop (in 64-wide tiles) that is split
+
+static int current_device() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return (dev >= 0 && dev < MAX_DEVICES) ? dev : 0;
+}
 #ifdef PM_RING_PROF
 static long long* g_ring_prof = nullptr;
 #endif
-static int g_split_min_nk = 24;     // PANDORA_SPLITK_MIN_NK: shortest K loop (in 64-wide tiles) that is split
+
+static void init_once() {
+  static const bool init = [] {
+    const char* m = getenv("PANDORA_SPLITK_MIN_NK");
+    if (m) g_split_min_nk = atoi(m);
+    const char* r = getenv("PANDORA_GEMM_RING");
+    if (r) g_ring = atoi(r);
+    const char* rw = getenv("PANDORA_GEMM_RING_MAX_WORK");
+    if (rw) g_ring_max_work = atoi(rw);
+    return true;
+  }();
+  (void)init;
+}
 
 static int choose_splits(int64_t M, int64_t N, int64_t K, int act, int* ktps) {
+  init_once();
   const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   const int nk = (int)((K + BK - 1) / BK);
   *ktps = nk;
@@ -1336,16 +1361,7 @@ static int choose_splits(int64_t M, int64_t N, int64_t K, int act, int* ktps) {
 }
 
 static void plan_split(GemmParams& p, void* workspace, size_t workspace_bytes) {
-  static const bool init = [] {
-    const char* m = getenv("PANDORA_SPLITK_MIN_NK");
-    if (m) g_split_min_nk = atoi(m);
-    const char* r = getenv("PANDORA_GEMM_RING");
-    if (r) g_ring = atoi(r);
-    const char* rw = getenv("PANDORA_GEMM_RING_MAX_WORK");
-    if (rw) g_ring_max_work = atoi(rw);
-    return true;
-  }();
-  (void)init;
+  init_once();
   int ktps;
   int s = choose_splits(p.M, p.N, p.K, p.act, &ktps);
   // fused statistics: from the main kernel's epilogue when the call runs unsplit (64-row blocks), from the
@@ -1377,13 +1393,13 @@ template <typename T> static void launch_reduce(const GemmParams& p, hipStream_t
 }
 
 static int num_cus() {
-  if (g_num_cus == 0) {
-    int dev = 0, n = 0;
-    (void)hipGetDevice(&dev);
+  const int dev = current_device();
+  if (g_num_cus[dev] == 0) {
+    int n = 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-    g_num_cus = n;
+    g_num_cus[dev] = n;
   }
-  return g_num_cus;
+  return g_num_cus[dev];
 }
 
 template <typename T, int AMODE, bool A32> static int launch1(const GemmParams& p, hipStream_t stream) {
@@ -1392,11 +1408,12 @@ template <typename T, int AMODE, bool A32> static int launch1(const GemmParams& 
   q.mtiles = (p.M + BM - 1) / BM;
   const int64_t nwork = (int64_t)q.mtiles * p.ntiles * p.splits;
   const int grid = (int)nwork;  // one work item per workgroup (see PERSIST in the kernel)
-  static bool attr_set = false;  // idempotent; a benign race sets the same value twice
-  if (!attr_set) {
+  static bool attr_set[MAX_DEVICES] = {false};  // per device; idempotent (a benign race sets the same value twice)
+  const int dev = current_device();
+  if (!attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, AMODE, A32>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
+    attr_set[dev] = true;
   }
   hipLaunchKernelGGL((gemm_kernel<T, AMODE, A32>), dim3(grid), dim3(256), lds, stream, q);
   if (p.splits > 1) launch_reduce<T>(p, stream);
@@ -1411,11 +1428,12 @@ template <typename T, int AMODE> static int launch_ring(const GemmParams& p, hip
   q.mtiles = (p.M + BM - 1) / BM;
   const int64_t nwork = (int64_t)q.mtiles * p.ntiles * p.splits;
   const int grid = (int)(nwork < num_cus() ? nwork : num_cus());
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[MAX_DEVICES] = {false};
+  const int dev = current_device();
+  if (!attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<T, AMODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
-    attr_set = true;
+    attr_set[dev] = true;
   }
   hipLaunchKernelGGL((gemm_ring_kernel<T, AMODE>), dim3(grid), dim3(512), RING_LDS, stream, q);
   if (p.splits > 1) launch_reduce<T>(p, stream);

@@ -62,8 +62,12 @@ class _ForwardGraph:
 
 
 class DDIMSampler:
-    def __init__(self, model, schedule="linear", use_graph=None, cfg_parallel=None, **kwargs):
+    def __init__(self, model, schedule="linear", use_graph=None, cfg_parallel=None, ops=None, **kwargs):
+        """`ops`: the op table for the fused update kernel; default = the one bound to model's U-Net.  Pass it
+        explicitly to run this sampler around a model whose U-Net is not ours (e.g. the reference's own
+        LatentVisualDiffusion shell: the sampler only needs the attributes of ddim.py:14,27-50,229-277)."""
         self.model = model
+        self._ops_override = ops
         self.cfg_parallel = cfg_parallel  # frame_parallel.CFGParallel: this rank runs ONE CFG branch
         self.ddpm_num_timesteps = model.num_timesteps
         self.schedule = schedule
@@ -71,11 +75,34 @@ class DDIMSampler:
         # HIP-graph replay of the forwards (single-GPU HipOps only; PANDORA_HIPGRAPH=0 disables)
         self.use_graph = (os.environ.get("PANDORA_HIPGRAPH", "1") != "0") if use_graph is None else use_graph
         self._graphs = {}
+        self._gen = None  # multi-rank noise generator (see _draw)
+
+    def _fp(self):
+        unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
+        return getattr(unet, "fp", None)
+
+    def _multi_rank(self):
+        return self.cfg_parallel is not None or self._fp() is not None
+
+    def _draw(self, shape, device):
+        """Standard-normal draw of CLIP-level shape.  Single process: the device RNG, as the reference
+        (lvdm/common.py:31-34).  Multi-rank (CFG pair and / or frame shards): every rank must consume the SAME
+        clip-level draw - the partners of a CFG pair apply the identical update, a frame shard takes its slice of
+        one clip - so all ranks draw the full tensor from a generator seeded with a value broadcast by rank 0."""
+        if not self._multi_rank():
+            return torch.randn(shape, device=device)
+        if self._gen is None:
+            import torch.distributed as dist
+            seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
+            t = seed.to(device) if dist.get_backend() == "nccl" else seed
+            dist.broadcast(t, src=0)
+            self._gen = torch.Generator(device="cpu").manual_seed(int(t.item()))
+        return torch.randn(shape, generator=self._gen).to(device)
 
     def _ops(self):
-        ops = getattr(self.model, "ops", None)
+        ops = self._ops_override or getattr(self.model, "ops", None)
         if ops is None:
-            ops = self.model.model.diffusion_model.ops
+            ops = getattr(self.model.model.diffusion_model, "ops", None)
         if ops is None:
             raise RuntimeError("the U-Net has no op table bound (UNetModel.bind(HipOps(...)))")
         return ops
@@ -164,7 +191,10 @@ class DDIMSampler:
 
         def replay(cc, uu):
             tensors = [v for d in (cc, uu or {}) for lst in d.values() for v in lst] + ([fs] if torch.is_tensor(fs) else [])
-            key = (tuple(x.shape), tuple((v.data_ptr(), tuple(v.shape)) for v in tensors), tuple(sorted(kwargs)))
+            # (a weight reload / .to() re-packs the kernel-side weights: the captured graph holds raw pointers to the
+            # old ones, so the U-Net's pack epoch is part of the key)
+            key = (tuple(x.shape), tuple((v.data_ptr(), tuple(v.shape)) for v in tensors), tuple(sorted(kwargs)),
+                   getattr(unet, "_pack_epoch", 0))
             g = self._graphs.get(key)
             if g is None:
                 self._graphs.clear()  # one live graph: its private pool holds a forward's activations
@@ -190,13 +220,30 @@ class DDIMSampler:
             # kernel takes the finished model output (e_u = None, cfg = 1)
             dims = list(range(1, e_c.dim()))
             v = e_u + cfg_scale * (e_c - e_u)
-            v = guidance_rescale * (v * (e_c.std(dim=dims, keepdim=True) / v.std(dim=dims, keepdim=True))) \
-                + (1.0 - guidance_rescale) * v
+            fp = self._fp()
+            if fp is None:
+                ratio = e_c.std(dim=dims, keepdim=True) / v.std(dim=dims, keepdim=True)
+            else:
+                # frame shards: the reference takes the std over the WHOLE (C, T, H, W) sample - one all-reduce of
+                # {sum, sum of squares} of both tensors and the element count, then the same unbiased estimator
+                ec64, v64 = e_c.double(), v.double()
+                part = torch.stack([ec64.sum(), (ec64 * ec64).sum(), v64.sum(), (v64 * v64).sum(),
+                                    torch.tensor(float(e_c.numel()), dtype=torch.float64, device=e_c.device)])
+                tot = fp.all_reduce_sum(part)
+                n = tot[4]
+                std = lambda s1, s2: ((s2 - s1 * s1 / n) / (n - 1)).clamp_min(0).sqrt()
+                ratio = (std(tot[0], tot[1]) / std(tot[2], tot[3])).to(v.dtype)
+            v = guidance_rescale * (v * ratio) + (1.0 - guidance_rescale) * v
             e_c, e_u, cfg_scale = v, None, 1.0
         sc = self.step_scalars(index, step)
         if sc["sigma"] != 0.0:
             if noise is None:
-                noise = torch.randn(x.shape, device=ops.device)
+                fp = self._fp()
+                if fp is None:
+                    noise = self._draw(x.shape, ops.device)
+                else:  # this rank's frames of ONE clip-level draw
+                    clip = tuple(x.shape[:2]) + (fp.total_frames,) + tuple(x.shape[3:])
+                    noise = fp.shard_frames(self._draw(clip, ops.device))
             noise = noise.to(device=ops.device, dtype=torch.float32).contiguous()
             sc["sigma"] *= float(temperature)
         else:
@@ -211,8 +258,26 @@ class DDIMSampler:
                       noise_fn=None, guidance_rescale=0.0, **kwargs):
         ops = self._ops()
         device = ops.device
-        img = torch.randn(shape, device=device) if x_T is None else x_T.to(device)
+        img = self._draw(shape, device) if x_T is None else x_T.to(device)
         img = img.to(torch.float32).contiguous()  # the loop state stays f32 (see module docstring)
+        fp = self._fp()
+        if fp is not None:
+            # frame-sharded U-Net: `shape`, x_T, the concat condition and the noise are CLIP-level here (as the
+            # caller of the reference's sampler passes them); this rank keeps its frames, the final latent is
+            # gathered.  c_crossattn stays whole (the U-Net slices the per-frame image tokens itself).
+            T_total = fp.total_frames
+            shard = lambda t: fp.shard_frames(t.to(device)) if torch.is_tensor(t) and t.dim() == 5 and t.shape[2] == T_total else t
+            img = shard(img)
+
+            def shard_cond(c):
+                if not isinstance(c, dict) or "c_concat" not in c:
+                    return c
+                return dict(c, c_concat=[shard(t) for t in c["c_concat"]])
+
+            cond, unconditional_conditioning = shard_cond(cond), shard_cond(unconditional_conditioning)
+            if noise_fn is not None:
+                user_noise = noise_fn
+                noise_fn = lambda i, shp: shard(user_noise(i, shape))
         timesteps = self.ddim_timesteps
         total_steps = timesteps.shape[0]
         time_range = np.flip(timesteps)
@@ -237,10 +302,11 @@ class DDIMSampler:
                 assert x0 is not None
                 img_orig = x0 if clean_cond else self.model.q_sample(x0, ts.cpu()).to(device)
                 img = (img_orig * mask + (1.0 - mask) * img).float().contiguous()
+            noise = noise_fn(i, shape) if noise_fn is not None else None
             img, pred_x0 = self.p_sample_ddim(img, cond, ts, index, temperature=temperature,
                                               unconditional_guidance_scale=unconditional_guidance_scale,
                                               unconditional_conditioning=unconditional_conditioning, fs=fs,
-                                              noise=noise_fn(i, shape) if noise_fn is not None else None, step=step,
+                                              noise=noise, step=step,
                                               guidance_rescale=guidance_rescale, **model_kwargs)
             if callback:
                 callback(i)
@@ -249,6 +315,8 @@ class DDIMSampler:
             if index % log_every_t == 0 or index == total_steps - 1:
                 intermediates["x_inter"].append(img)
                 intermediates["pred_x0"].append(pred_x0)
+        if fp is not None:
+            img = fp.gather_frames(img)
         if precision is not None and isinstance(precision, torch.dtype):
             img = img.to(precision)
         return img, intermediates

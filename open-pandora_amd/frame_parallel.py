@@ -56,6 +56,13 @@ class FrameParallel:
         dist.all_gather(parts, x_local.contiguous(), group=self.group)
         return torch.cat(parts, dim=dim)
 
+    def all_reduce_sum(self, t):
+        """sum over the frame group (sampler-level reductions, e.g. the std of rescale_noise_cfg)"""
+        t = t.contiguous().clone()
+        _host_staged_sync(t, self.group)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
     # ---- the three in-forward exchanges ---------------------------------------------------------
     def reduce_stats(self, partial, local_count):
         """partial f32 [NI, groups, 2] local {sum, sumsq} -> (all-rank totals, total element count)."""

@@ -337,3 +337,18 @@ class HipOps:
         rc = self.lib.pm_unpack_output(_ptr(y), _ptr(out), C, F, P, self._in_dt(y), self._stream())
         capi.check(rc, "pm_unpack_output")
         return out
+
+
+def memory_efficient_attention(q, k, v, attn_bias=None, op=None, scale=None, ops=None):
+    """The reference's kernel seam (attention.py:64-67 rebinds CrossAttention.forward to efficient_forward, which
+    calls `xformers.ops.memory_efficient_attention(q, k, v, attn_bias=None, op=None)` on contiguous
+    `(b * heads, n, 64)` tensors, attention.py:166-175) served by pm_attention: same argument list, same layout,
+    same result `(b * heads, n_q, 64)`.  Each (batch, head) pair is one batch element of a 1-head call."""
+    if attn_bias is not None:
+        raise NotImplementedError("attn_bias: the reference passes None (attention.py:175)")
+    if q.dim() != 3 or q.shape[-1] != 64 or k.shape != v.shape or k.shape[0] != q.shape[0] or k.shape[-1] != 64:
+        raise ValueError(f"expected (b*heads, n, 64) tensors, got {tuple(q.shape)}, {tuple(k.shape)}, {tuple(v.shape)}")
+    if scale is not None and abs(scale - 64 ** -0.5) > 1e-9:
+        raise NotImplementedError("pm_attention applies the softmax scale 64^-1/2 of attention.py:24")
+    ops = ops or HipOps(q.dtype, q.device)
+    return ops.attention(q.contiguous(), k.contiguous(), v.contiguous(), heads=1)

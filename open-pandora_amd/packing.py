@@ -25,3 +25,40 @@ def geglu_perm(n_out):
 def pack_geglu(w, b):
     perm = geglu_perm(w.shape[0] // 2)
     return w[perm].contiguous(), b[perm].contiguous()
+
+
+class PackedWeights:
+    """Mixin of the modules that keep kernel-side packed copies of their parameters (`self._packed`): the copies
+    must die whenever the parameters change - through `load_state_dict` on the module OR on any parent (the
+    reference's loaders call it on the whole LatentVisualDiffusion, scripts/evaluation/inference.py:27-52), through
+    `.to()` / `.half()` / `.cuda()`, or through in-place edits (an optimizer step).  `_pack_epoch` counts the
+    invalidations so that holders of derived state (the sampler's captured HIP graphs, which keep raw pointers to
+    the packed tensors) can notice."""
+
+    def _init_packed(self):
+        self._packed, self._packed_fp, self._pack_epoch = None, None, 0
+        self.register_load_state_dict_post_hook(lambda module, _incompatible: module.invalidate_packed())
+
+    def invalidate_packed(self):
+        self._packed, self._packed_fp = None, None
+        self._pack_epoch += 1
+
+    def _apply(self, fn, *args, **kwargs):  # .to() / .half() / .float() / .cuda() of this module or a parent
+        self.invalidate_packed()
+        return super()._apply(fn, *args, **kwargs)
+
+    def _fingerprint(self):
+        """(version counter, address) of a fixed sample of the parameters: an in-place edit bumps the version, a
+        re-assignment changes the address.  ~40 tensors: microseconds per forward."""
+        ps = list(self.parameters())
+        step = max(1, len(ps) // 40)
+        return (len(ps),) + tuple((p._version, p.data_ptr()) for p in ps[::step])
+
+    def packed(self):
+        """the current packed weight set, rebuilt (prepare()) if the parameters changed since it was made"""
+        if self._packed is None or self._packed_fp != self._fingerprint():
+            if self._packed is not None:
+                self.invalidate_packed()
+            self.prepare()
+            self._packed_fp = self._fingerprint()
+        return self._packed

@@ -16,6 +16,8 @@ Graph (tokens as [rows, channels] matrices, f32 residual stream like the U-Net):
 import torch
 import torch.nn as nn
 
+from . import packing
+
 
 class PerceiverAttention(nn.Module):
     def __init__(self, *, dim, dim_head=64, heads=8):
@@ -34,7 +36,7 @@ def FeedForward(dim, mult=4):
     return nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, inner, bias=False), nn.GELU(), nn.Linear(inner, dim, bias=False))
 
 
-class Resampler(nn.Module):
+class Resampler(packing.PackedWeights, nn.Module):
     def __init__(self, dim=1024, depth=8, dim_head=64, heads=16, num_queries=8, embedding_dim=768,
                  output_dim=1024, ff_mult=4, video_length=None):
         super().__init__()
@@ -48,10 +50,12 @@ class Resampler(nn.Module):
         self.norm_out = nn.LayerNorm(output_dim)
         self.layers = nn.ModuleList([nn.ModuleList([PerceiverAttention(dim=dim, dim_head=dim_head, heads=heads),
                                                     FeedForward(dim=dim, mult=ff_mult)]) for _ in range(depth)])
-        self.heads, self.ops, self._packed = heads, None, None
+        self.heads, self.ops = heads, None
+        self._init_packed()
 
     def bind(self, ops):
-        self.ops, self._packed = ops, None
+        self.ops = ops
+        self.invalidate_packed()
         return self
 
     def prepare(self):
@@ -75,9 +79,7 @@ class Resampler(nn.Module):
         """x [B, n1, embedding_dim] image tokens -> [B, num_queries(*video_length), output_dim]."""
         if self.ops is None:
             raise RuntimeError("Resampler has no op table bound (Resampler.bind(HipOps(...)))")
-        if self._packed is None:
-            self.prepare()
-        ops, W, heads = self.ops, self._packed, self.heads
+        ops, W, heads = self.ops, self.packed(), self.heads
         B, n1, E = x.shape
         nq, D = W["latents"].shape
         inner = heads * 64

@@ -178,10 +178,11 @@ class TimestepEmbedSequential(nn.Sequential):
 # ------------------------------------------------------------------------------------------------
 class _Ctx:
     """Per-forward execution state."""
-    __slots__ = ("ops", "fp", "F", "H", "W", "emb_bias", "ctx_text", "ctx_img", "w", "stats", "kv_text", "kv_img")
+    __slots__ = ("ops", "fp", "F", "H", "W", "emb_bias", "ctx_text", "ctx_img", "w", "stats", "kv_text", "kv_img",
+                 "img_shared")
 
 
-class UNetModel(nn.Module):
+class UNetModel(packing.PackedWeights, nn.Module):
     def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
                  dropout=0.0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, context_dim=None,
                  use_scale_shift_norm=False, resblock_updown=False, num_heads=-1, num_head_channels=-1,
@@ -267,17 +268,13 @@ class UNetModel(nn.Module):
 
         self.ops = None
         self.fp = None
-        self._packed = None
+        self._init_packed()
 
-    # ---- kernel-side weights -------------------------------------------------------------------
-    def load_state_dict(self, *a, **k):
-        self._packed = None  # packed copies are stale
-        return super().load_state_dict(*a, **k)
-
+    # ---- kernel-side weights (invalidated by packing.PackedWeights on every kind of parameter change) ----
     def bind(self, ops, fp=None):
         """Select the op table (HipOps in production) and optional frame-parallel context."""
         self.ops, self.fp = ops, fp
-        self._packed = None
+        self.invalidate_packed()
         return self
 
     def prepare(self):
@@ -458,9 +455,10 @@ class UNetModel(nn.Module):
                 lo, hi = e["a2_kv_slice"]
                 kv_t = c.kv_text[:, lo:hi].unsqueeze(0)  # [1, 77, 2*inner] view of the batched projection
                 k2 = v2 = None
-                if "a2_kv_ip_slice" in e:
+                if "a2_kv_ip_slice" in e and c.kv_img is not None:
                     lo, hi = e["a2_kv_ip_slice"]
-                    kv_i = c.kv_img[:, lo:hi].unflatten(0, (F, -1))  # [F, 16, 2*inner] view
+                    # [F, 16, 2*inner] view of the per-frame tokens, or [1, n, 2*inner] shared by every frame
+                    kv_i = c.kv_img[:, lo:hi].unsqueeze(0) if c.img_shared else c.kv_img[:, lo:hi].unflatten(0, (F, -1))
                     k2, v2 = kv_i[..., :inner], kv_i[..., inner:]
                 a = ops.attention(q, kv_t[..., :inner], kv_t[..., inner:], heads, k2, v2, 1.0)
             h = ops.gemm(a.view(F * P, inner), *e[f"a{which}_out"], residual=h, stream=True)
@@ -543,25 +541,37 @@ class UNetModel(nn.Module):
         # every ResBlock's  b_conv1 + b_emb + W_emb . silu(emb)  in one launch
         return ops.gemv(W["emb_all"][0], emb, W["emb_all"][1], silu_in=True)
 
-    @torch.no_grad()
     def forward(self, x, timesteps, context=None, features_adapter=None, fs=None, **kwargs):
         """x (1, C_in, t_local, h, w), timesteps (1,), context (1, 77 + 16*T, 1024), fs (1,) ->
         (1, C_out, t_local, h, w) in f32.  In frame-sharded mode x holds this rank's
         frames and `context` is the full-clip context (image tokens are sliced by `fp`)."""
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # the training seam (model.py:926-942 -> ddpm3d.py:701-706 -> apply_model): the op tables of this
+            # package are forward-only kernels on detached, packed weights - no autograd graph would be built and
+            # loss.backward() would fail (or silently train nothing) far from here
+            raise RuntimeError(
+                "open_pandora_amd.unet.UNetModel is an inference module: called in training mode with autograd "
+                "enabled (WorldModel.training_step reaches the U-Net through LatentDiffusion.p_losses).  Train with the "
+                "reference's eager lvdm UNetModel - the state_dict keys are identical, so the trained weights load "
+                "here - or call under .eval() / torch.no_grad() for inference.")
+        with torch.no_grad():
+            return self._forward(x, timesteps, context, features_adapter, fs, **kwargs)
+
+    def _forward(self, x, timesteps, context=None, features_adapter=None, fs=None, **kwargs):
         if self.ops is None:
             raise RuntimeError("UNetModel.bind(ops) must be called before forward (no implicit CPU fallback)")
         _unsupported(features_adapter is not None, "features_adapter")
-        if self._packed is None:
-            self.prepare()
+        packed = self.packed()
         b, cin, t, hh, ww = x.shape
         assert b == 1, "the reference path runs batch size 1 (model.py:794)"
         c = _Ctx()
-        c.ops, c.fp, c.w = self.ops, self.fp, self._packed
+        c.ops, c.fp, c.w = self.ops, self.fp, packed
         c.stats = {}  # data_ptr -> (GroupNorm totals, shape) left behind by the op that wrote that stream tensor
         c.F, c.H, c.W = t, hh, ww
         ops = c.ops
         T_total = t if c.fp is None else c.fp.total_frames
         ctx = context[0].to(device=ops.device, dtype=ops.dtype)
+        c.img_shared = False
         if ctx.shape[0] == 77 + T_total * 16:  # per-frame image conditioning (openaimodel3d.py:559-564)
             c.ctx_text = ctx[:77].contiguous()
             img = ctx[77:].reshape(T_total, 16, -1)
@@ -569,9 +579,14 @@ class UNetModel(nn.Module):
                 img = img[c.fp.frame_offset:c.fp.frame_offset + t]
             c.ctx_img = img.reshape(t * 16, -1).contiguous()
         else:
-            raise NotImplementedError("context without per-frame image tokens")
+            # openaimodel3d.py:565-566: the same context for every frame; CrossAttention still splits it at the
+            # hard-coded text length 77 (attention.py:89-99): what lies beyond are image tokens shared by all frames
+            c.ctx_text = ctx[:77].contiguous()
+            c.ctx_img = ctx[77:].contiguous() if ctx.shape[0] > 77 else None
+            c.img_shared = True
         c.kv_text = ops.gemm(c.ctx_text, c.w["kv_text_all"]) if c.w["kv_text_all"] is not None else None
-        c.kv_img = ops.gemm(c.ctx_img, c.w["kv_img_all"]) if c.w["kv_img_all"] is not None else None
+        c.kv_img = (ops.gemm(c.ctx_img, c.w["kv_img_all"])
+                    if c.w["kv_img_all"] is not None and c.ctx_img is not None else None)
         c.emb_bias = self._embed(c, timesteps, fs)
 
         if x.dtype == torch.float32:

@@ -118,6 +118,20 @@ def gen_unet_small():
     save("unet_small.npz", **out)
 
 
+def gen_unet_ctx():
+    """The `else` branch of UNetModel.forward's context handling (openaimodel3d.py:565-566): a context that is not
+    77 + 16 t tokens long is repeated for every frame; CrossAttention still splits it at token 77."""
+    out = {}
+    ref = rh.reference_unet(model_channels=64)
+    ref.load_state_dict(synth.synth_state_dict(ref, seed=WEIGHT_SEED))
+    ins, _, _ = _small_setup(64, 8, 8)
+    x = torch.cat([ins["x_T"], ins["c_concat"]], 1)
+    for L, tag in gr.UNET_CTX_CASES:
+        with torch.no_grad():
+            out[tag] = ref(x, torch.tensor([500]), context=ins["c_crossattn"][:, :L], fs=torch.tensor([15])).numpy()
+    save("unet_small_ctx.npz", **out)
+
+
 def gen_ddim_small():
     import lvdm.models.samplers.ddim as refddim
     out = {}
@@ -297,6 +311,7 @@ def gen_full_72x128(traj_steps=0):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full-72x128", action="store_true")
+    ap.add_argument("--ctx", action="store_true")
     ap.add_argument("--traj-72x128", type=int, default=0)
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--traj", action="store_true")
@@ -305,6 +320,10 @@ if __name__ == "__main__":
     ap.add_argument("--rescale", action="store_true")
     ap.add_argument("--resampler", action="store_true")
     a = ap.parse_args()
+    if a.ctx:
+        assert rh.available()
+        gen_unet_ctx()
+        sys.exit(0)
     if a.full_72x128 or a.traj_72x128:
         assert rh.available()
         gen_full_72x128(a.traj_72x128)
@@ -331,5 +350,6 @@ if __name__ == "__main__":
         gen_schedule()
         gen_modules()
         gen_unet_small()
+        gen_unet_ctx()
         gen_ddim_small()
         gen_ddim_rescale()

@@ -64,7 +64,7 @@ class AttrDict(dict):
         return AttrDict(v) if isinstance(v, dict) else v
 
 
-def reference_diffusion(unet_overrides=None, base_scale=0.7):
+def reference_diffusion(unet_overrides=None, base_scale=0.7, unet_target="lvdm.modules.networks.openaimodel3d.UNetModel"):
     """LatentVisualDiffusion (ddpm3d.py:1036) with Identity condition stages and first stage."""
     _install_shims()
     import torch
@@ -78,7 +78,7 @@ def reference_diffusion(unet_overrides=None, base_scale=0.7):
         cond_stage_trainable=False, conditioning_key="hybrid", image_size=[40, 64], channels=4,
         scale_by_std=False, scale_factor=0.18215, use_ema=False, uncond_type="empty_seq",
         use_dynamic_rescale=True, base_scale=base_scale, fps_condition_type="fps", perframe_ae=True,
-        unet_config=AttrDict(target="lvdm.modules.networks.openaimodel3d.UNetModel", params=AttrDict(up)),
+        unet_config=AttrDict(target=unet_target, params=AttrDict(up)),
         first_stage_config=ident, cond_stage_config=ident, img_cond_stage_config=ident,
         image_proj_stage_config=ident)
     model = LatentVisualDiffusion(**cfg).eval()

@@ -34,17 +34,17 @@ def _build(fp=None):
     return LatentVisualDiffusion(m)
 
 
-def _sample(pm, fp, S, eta, cfgp=None):
+def _sample(pm, fp, S, eta, cfgp=None, guidance_rescale=0.0, inject_noise=True):
+    """The sampler's call surface is CLIP-level whether or not the U-Net is frame-sharded: x_T, the concat
+    condition, `shape` and the injected noise cover all 16 frames; with `fp` every rank keeps its frames inside
+    and the returned latent is the gathered clip."""
     ins, cond, uc = gr.sampler_inputs(8, 8)
     ns = gr.noises(ins["x_T"].shape, S)
-    sh = (lambda t: t) if fp is None else fp.shard_frames
-    cond = {"c_crossattn": cond["c_crossattn"], "c_concat": [sh(cond["c_concat"][0])]}
-    uc = {"c_crossattn": uc["c_crossattn"], "c_concat": [sh(uc["c_concat"][0])]}
-    F = 16 if fp is None else fp.local_frames
-    y, _ = DDIMSampler(pm, cfg_parallel=cfgp).sample(S=S, batch_size=1, shape=(4, F, 8, 8), conditioning=cond, verbose=False,
+    y, _ = DDIMSampler(pm, cfg_parallel=cfgp).sample(S=S, batch_size=1, shape=(4, 16, 8, 8), conditioning=cond, verbose=False,
                                   unconditional_guidance_scale=4.0, unconditional_conditioning=uc, eta=eta,
-                                  fs=torch.tensor([15]), timestep_spacing="uniform_trailing", x_T=sh(ins["x_T"]),
-                                  noise_fn=lambda i, shape: sh(ns[i]))
+                                  fs=torch.tensor([15]), timestep_spacing="uniform_trailing", x_T=ins["x_T"],
+                                  noise_fn=(lambda i, shape: ns[i]) if inject_noise else None,
+                                  guidance_rescale=guidance_rescale)
     return y
 
 
@@ -54,7 +54,7 @@ def _worker(rank, world, port, S, eta, out):
     try:
         fp = FrameParallel(16)
         pm = _build(fp)
-        y = fp.gather_frames(_sample(pm, fp, S, eta))
+        y = _sample(pm, fp, S, eta)
         if rank == 0:
             torch.save({"y": y, "calls": fp.calls}, out)
     finally:
@@ -82,8 +82,6 @@ def _hybrid_worker(rank, world, port, S, eta, out):
         fp, cfgp = make_hybrid(16)
         pm = _build(fp)
         y = _sample(pm, fp, S, eta, cfgp)
-        if fp is not None:
-            y = fp.gather_frames(y)
         torch.save({"y": y, "fp_calls": None if fp is None else fp.calls, "cfg_calls": cfgp.calls}, f"{out}.{rank}")
     finally:
         dist.destroy_process_group()
@@ -105,3 +103,30 @@ def test_cfg_pair_plus_frame_sharding_matches_single_process(tmp_path, world, S,
         else:  # ONE forward per step and rank
             assert got["fp_calls"] == {"reduce_stats": 105 * S, "exchange_halo": 88 * S, "all_to_all": 32 * S,
                                        "gather_kv": 2 * S}
+
+
+def _rescale_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fp, cfgp = make_hybrid(16)
+        pm = _build(fp)
+        y = _sample(pm, fp, 3, 1.0, cfgp, guidance_rescale=0.7)
+        # and once with the sampler's OWN noise (no injection): every rank must consume one clip-level draw
+        z = _sample(pm, fp, 3, 0.5, cfgp, inject_noise=False)  # (eta 1 is NaN at tiny S: SURVEY 0.5)
+        torch.save({"y": y, "z": z}, f"{out}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_guidance_rescale_and_own_noise_under_cfg_pair_and_frame_shards(tmp_path):
+    """rescale_noise_cfg takes its std over the WHOLE sample (utils_diffusion.py:147-158) - frame shards
+    must all-reduce it; and with eta > 0 and no injected noise the ranks must still agree (one clip-level draw from
+    a generator seeded by rank 0), or the partners of a CFG pair diverge silently."""
+    out = str(tmp_path / "y.pt")
+    mp.spawn(_rescale_worker, args=(4, _free_port(), out), nprocs=4, join=True)
+    want = _sample(_build(None), None, 3, 1.0, guidance_rescale=0.7)
+    got = [torch.load(f"{out}.{r}") for r in range(4)]
+    for r in range(4):
+        assert ((got[r]["y"] - want).norm() / want.norm()).item() < 2e-5, r
+        assert torch.equal(got[r]["z"], got[0]["z"]) and torch.isfinite(got[r]["z"]).all(), r
