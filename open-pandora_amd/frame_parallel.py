@@ -5,9 +5,13 @@ Rank r owns frames [r*T/N, (r+1)*T/N) of every activation; weights and the text 
 replicated.  Everything in the U-Net is per-frame except three exchanges, which this
 object provides to UNetModel:
 
-  reduce_stats   GroupNorm over (T,H,W): all-reduce of 32 x {sum, sumsq} f32 partials (256 B, latency);
-  exchange_halo  temporal 3-tap conv: one boundary frame to each neighbour (point-to-point, the clip
-                 ends keep zero padding);
+  exchange_stats_halo
+                 one grouped point-to-point exchange per temporal-conv stage: the (T,H,W)-GroupNorm partial sums
+                 (256 B to every rank of the group) travel with the raw boundary frames (to the two neighbours;
+                 the clip ends keep zero padding) - 88 exchanges per forward where an all-reduce PLUS a halo
+                 exchange per stage made 176;
+  reduce_stats   the remaining (T,H,W) GroupNorms (one per TemporalTransformer): all-reduce of 256 B;
+  exchange_halo  (the separate halo form, kept for callers that already hold global statistics);
   frames_to_pixels / pixels_to_frames
                  TemporalTransformer: one all-to-all in (after the GroupNorm) and one out (before
                  proj_out) re-shard frames <-> pixels, so its projections, both temporal
@@ -42,7 +46,7 @@ class FrameParallel:
         self.local_frames = total_frames // self.world
         self.frame_offset = self.rank * self.local_frames
         self.backend = dist.get_backend(group)
-        self.calls = {"reduce_stats": 0, "exchange_halo": 0, "all_to_all": 0}
+        self.calls = {"reduce_stats": 0, "exchange_halo": 0, "all_to_all": 0, "stats_halo": 0}
 
     # ---- clip-level helpers (sampler boundary) --------------------------------------------------
     def shard_frames(self, x, dim=2):
@@ -90,6 +94,40 @@ class FrameParallel:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
         return lo, hi
+
+    def exchange_stats_halo(self, x, P, partial, local_count):
+        """ONE grouped point-to-point exchange per temporal-conv stage instead of an all-reduce plus a halo
+        exchange: every rank sends its (T,H,W)-GroupNorm partial sums (256 B) to every other rank of the frame
+        group and its RAW boundary frames of x [F_local*P, C] to the two neighbours - raw, because the normalised
+        halo needs the global statistics that travel in the same message; the receiver normalises the (at most
+        two) halo frames itself with the totals it has just formed.  Totals are summed in rank order on every
+        rank (bitwise identical everywhere).  -> (totals [1, groups, 2], total count, raw frame before my first
+        or None, raw frame after my last or None)."""
+        self.calls["stats_halo"] += 1
+        part = partial.contiguous()
+        first = x[:P].contiguous()
+        last = x[(self.local_frames - 1) * P:].contiguous()
+        _host_staged_sync(x, self.group)
+        lo = torch.empty_like(first) if self.rank > 0 else None
+        hi = torch.empty_like(first) if self.rank < self.world - 1 else None
+        parts = [part if r == self.rank else torch.empty_like(part) for r in range(self.world)]
+        ops = []
+        for r in range(self.world):
+            if r != self.rank:
+                ops += [dist.P2POp(dist.isend, part, self._global(r), self.group),
+                        dist.P2POp(dist.irecv, parts[r], self._global(r), self.group)]
+        if self.rank > 0:
+            ops += [dist.P2POp(dist.isend, first, self._global(self.rank - 1), self.group),
+                    dist.P2POp(dist.irecv, lo, self._global(self.rank - 1), self.group)]
+        if self.rank < self.world - 1:
+            ops += [dist.P2POp(dist.isend, last, self._global(self.rank + 1), self.group),
+                    dist.P2POp(dist.irecv, hi, self._global(self.rank + 1), self.group)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        tot = parts[0].clone()
+        for r in range(1, self.world):
+            tot += parts[r]
+        return tot, float(local_count) * self.world, lo, hi
 
     def _a2a(self, src):
         dst = torch.empty_like(src)

@@ -419,10 +419,20 @@ class UNetModel(packing.PackedWeights, nn.Module):
                              stats=(1, 32))
         ident = h
         for i, (gb, wp, b) in enumerate(e["tconv"]):
-            t = self._gn(c, h, gb, 1e-5, True, False, totals=tot)
             lo_h = hi_h = None
-            if c.fp is not None:
-                lo_h, hi_h = c.fp.exchange_halo(t, P)
+            if c.fp is None:
+                t = self._gn(c, h, gb, 1e-5, True, False, totals=tot)
+            else:
+                # frame shards: ONE grouped exchange carries this stage's GroupNorm partial sums and the raw boundary
+                # frames; the halo frames are normalised here, with the same global totals as this rank's own frames
+                part = tot if tot is not None else ops.groupnorm_stats(h, 1, 32)
+                tot_g, count, lo_raw, hi_raw = c.fp.exchange_stats_halo(h, P, part, h.shape[0] * (h.shape[1] // 32))
+                glob = lambda _part, _cnt: (tot_g, count)
+                t = ops.groupnorm(h, gb[0], gb[1], 1e-5, 1, True, stats_reduce=glob, totals=part)
+                if lo_raw is not None:
+                    lo_h = ops.groupnorm(lo_raw, gb[0], gb[1], 1e-5, 1, True, stats_reduce=glob, totals=part)
+                if hi_raw is not None:
+                    hi_h = ops.groupnorm(hi_raw, gb[0], gb[1], 1e-5, 1, True, stats_reduce=glob, totals=part)
             if i < 3:
                 h, tot = ops.conv_t3(t, wp, b, c.F, P, halo_lo=lo_h, halo_hi=hi_h, stream=True, stats=(1, 32))
             else:

@@ -71,8 +71,11 @@ def test_frame_sharded_sampling_matches_single_process(tmp_path, world, S, eta):
     assert err < 2e-5, err
     # 2 forwards/step: 105 (T,H,W) GroupNorms, 88 temporal convs, 17 TemporalTransformers (2 all-to-all) each
     # (the 1x1-pixel middle block of this 8x8 test latent cannot be pixel-sharded: K|V all-gather there)
-    assert got["calls"] == {"reduce_stats": 105 * 2 * S, "exchange_halo": 88 * 2 * S, "all_to_all": 32 * 2 * S,
-                            "gather_kv": 2 * 2 * S}
+    # per forward: 88 temporal-conv stages = 88 grouped {statistics + halo} exchanges, the 17 TemporalTransformer
+    # GroupNorms keep their all-reduce, 2 all-to-alls per pixel-shardable transformer: 139 collectives (was 227)
+    assert got["calls"] == {"reduce_stats": 17 * 2 * S, "exchange_halo": 0, "stats_halo": 88 * 2 * S,
+                            "all_to_all": 32 * 2 * S, "gather_kv": 2 * 2 * S}
+    assert sum(got["calls"].values()) // (2 * S) == 139
 
 
 def _hybrid_worker(rank, world, port, S, eta, out):
@@ -101,8 +104,8 @@ def test_cfg_pair_plus_frame_sharding_matches_single_process(tmp_path, world, S,
         if world == 2:
             assert got["fp_calls"] is None
         else:  # ONE forward per step and rank
-            assert got["fp_calls"] == {"reduce_stats": 105 * S, "exchange_halo": 88 * S, "all_to_all": 32 * S,
-                                       "gather_kv": 2 * S}
+            assert got["fp_calls"] == {"reduce_stats": 17 * S, "exchange_halo": 0, "stats_halo": 88 * S,
+                                       "all_to_all": 32 * S, "gather_kv": 2 * S}
 
 
 def _rescale_worker(rank, world, port, out):
