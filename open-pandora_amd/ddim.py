@@ -38,21 +38,43 @@ def make_ddim_timesteps(method, num_ddim, num_ddpm):
 class _ForwardGraph:
     """The U-Net forwards of one DDIM step (cond and, with CFG, uncond) captured once into a HIP graph
     and replayed every step: ~2000 kernel launches per step become one graph launch.  Inputs live in
-    static buffers (latent, timestep); the condition tensors are read in place at replay."""
+    static buffers (latent, timestep); the condition tensors are read in place at replay.
+
+    The two forwards of a CFG step are independent (ddim.py:233-234 runs them back to back): they are captured
+    on TWO streams forked inside the graph, so their kernels overlap on the device - the forward is a chain of
+    ~1100 dependent launches averaging 25 us, half of them on grids that do not fill 256 CUs (the 10x16 and 5x8
+    levels) and each with a ramp and a tail; a second, independent chain fills those holes.
+    (PANDORA_CFG_STREAMS=0: one stream, the two forwards in sequence.)"""
 
     def __init__(self, model, x, t, c, uc, fs, kwargs):
         self.x = x.clone()
         self.t = t.clone()
         dev = x.device
+        two = uc is not None and os.environ.get("PANDORA_CFG_STREAMS", "1") != "0"
         side = torch.cuda.Stream(device=dev)
+        other = torch.cuda.Stream(device=dev) if two else None
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):  # warm-up outside capture: packs weights, sizes the allocator
             model.apply_model(self.x, self.t, c, fs=fs, **kwargs)
         torch.cuda.current_stream(dev).wait_stream(side)
+        if two:  # and the second stream's split-K workspace (HipOps keeps one per stream)
+            other.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(other):
+                model.apply_model(self.x, self.t, uc, fs=fs, **kwargs)
+            torch.cuda.current_stream(dev).wait_stream(other)
+            torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
+            main = torch.cuda.current_stream(dev)
+            if two:
+                other.wait_stream(main)  # fork
+                with torch.cuda.stream(other):
+                    self.e_u = model.apply_model(self.x, self.t, uc, fs=fs, **kwargs)
             self.e_c = model.apply_model(self.x, self.t, c, fs=fs, **kwargs)
-            self.e_u = model.apply_model(self.x, self.t, uc, fs=fs, **kwargs) if uc is not None else None
+            if two:
+                main.wait_stream(other)  # join
+            else:
+                self.e_u = model.apply_model(self.x, self.t, uc, fs=fs, **kwargs) if uc is not None else None
 
     def __call__(self, x, t):
         self.x.copy_(x)

@@ -45,7 +45,9 @@ class HipOps:
         # split-K scratch for the GEMM family (deep levels: few output tiles, long K); one buffer per
         # op table is enough because every launch on the stream is ordered after the previous reduce
         self.ws_bytes = int(workspace_mb) << 20
-        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.device) if self.ws_bytes else None
+        # ... per STREAM: the sampler runs the cond and the uncond forward of a step on two streams, and two
+        # split-K calls in flight at once must not share their slabs
+        self._workspaces = {}
 
     # -- helpers ---------------------------------------------------------------------------------
     def _stream(self):
@@ -54,6 +56,18 @@ class HipOps:
         if self._raw_stream is not None:
             return self._raw_stream(self._dev_index)
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    @property
+    def workspace(self):
+        """split-K scratch of the CURRENT stream (allocated on first use; inside a graph capture it comes from
+        the graph's pool, so warm every stream up before capturing)"""
+        if not self.ws_bytes:
+            return None
+        key = self._stream()
+        ws = self._workspaces.get(key)
+        if ws is None:
+            ws = self._workspaces[key] = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.device)
+        return ws
 
     def _rows(self, t, f32_ok=False):
         """(row stride in elements) of a 2-D, last-dim-contiguous view."""
