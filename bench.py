@@ -96,6 +96,17 @@ class TimedOps:
             self.attn_big = (self.attn_big[0], self.attn_big[1] + fl)
         return r[0]
 
+    def attention_fp8(self, q, k, v, heads, *args, **kw):
+        B, nq, _ = q.shape
+        fl = 4.0 * nq * k.shape[1] * 64 * heads * B
+        r = self._timed("attention", fl, self._ops.attention_fp8, q, k, v, heads, *args, **kw)
+        if not self.enabled:
+            return r
+        if nq == k.shape[1] and nq >= 9216:
+            self.attn_big[0].append(r[1])
+            self.attn_big = (self.attn_big[0], self.attn_big[1] + fl)
+        return r[0]
+
     def summary(self):
         out = {}
         for fam in KERNELS:
@@ -135,6 +146,11 @@ def main():
                     help="kernel-work runs: measure one resolution (the driver line always carries both)")
     ap.add_argument("--res", default=None, help=argparse.SUPPRESS)  # (round-1 spelling of --only)
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
+    ap.add_argument("--fp8-attention", action="store_true",
+                    help="spatial self-attention on pm_attention_fp8 (block-scaled e4m3 MFMA): BASELINE configs[4]")
+    ap.add_argument("--multiround", type=int, default=0,
+                    help="also time an N-round autoregressive 576x1024 generation (configs[4]: 5 rounds = 10 s of video): "
+                         "per round AE-encode 4 frames, 50 CFG DDIM steps, AE-decode 16 frames")
     a = ap.parse_args()
     only = a.only or a.res
 
@@ -159,7 +175,7 @@ def main():
     from open_pandora_amd.ops_hip import HipOps
 
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
-    ops = TimedOps(HipOps(dt, dev))
+    ops = TimedOps(HipOps(dt, dev, fp8_attention=a.fp8_attention))
     pm0 = factory.build_diffusion("320x512", ops)  # the two shipped configs share the U-Net (1 516 tensors)
     unet = pm0.model.diffusion_model
     fp = cfgp = None
@@ -274,6 +290,42 @@ def main():
         decode_ms = 1e3 * (time.perf_counter() - t1)
         assert frames.shape == (1, 3, T, 8 * h, 8 * w) and torch.isfinite(frames).all()
 
+    # BASELINE configs[4]: N-round autoregressive generation at 576x1024 through the caller surface
+    # (wm.DiffusionRunner.generate_multiround = ChatWM.generate_video_mutliround, model.py:1094-1129), 1 GPU
+    multi = None
+    if a.multiround and world == 1:
+        from open_pandora_amd import wm
+        from open_pandora_amd.autoencoder import AutoencoderKL
+        from open_pandora_amd.ddpm import LatentVisualDiffusion
+        r = dict(factory.RESOLUTIONS["576x1024"])
+        r.pop("default_fs")
+        pm2 = LatentVisualDiffusion(unet, linear_start=0.00085, linear_end=0.012, timesteps=1000, parameterization="v",
+                                    rescale_betas_zero_snr=True, conditioning_key="hybrid", use_dynamic_rescale=True,
+                                    scale_factor=0.18215, channels=4, **r)
+        with torch.device("meta"):
+            ae = AutoencoderKL()
+        ae.load_state_dict({k: synth.synth_tensor(k, tuple(v.shape), 20230211, dev) for k, v in ae.state_dict().items()},
+                           assign=True)
+        ae.bind(ops)
+        ins = synth.synth_inputs(72, 128, T, seed=123)
+        text, img = ins["c_crossattn"][:, :77].to(dev), ins["c_crossattn"][:, 77:].to(dev)
+        uct, uci = ins["uc_crossattn"][:, :77].to(dev), ins["uc_crossattn"][:, 77:].to(dev)
+        runner = wm.DiffusionRunner(pm2, lambda im: img if float(im.abs().sum()) > 0 else uci, uct,
+                                    ae.encode_first_stage, ae.decode_first_stage)
+        frame0 = synth.uniform_pm1(3 * 576 * 1024, 123, "bench/frame0", dev).reshape(3, 1, 576, 1024)
+        kw = dict(n_samples=1, ddim_steps=50, ddim_eta=1.0, unconditional_guidance_scale=4.0, fs=15,
+                  timestep_spacing="uniform_trailing")
+        runner.generate_multiround([text], frame0, frame0[None, :, 0], **dict(kw, ddim_steps=2))  # warm-up (graph, AE packing)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        video = runner.generate_multiround([text] * a.multiround, frame0, frame0[None, :, 0], **kw)
+        torch.cuda.synchronize()
+        dtm = time.perf_counter() - t0
+        assert video.shape == (1, 1, 3, 12 * (a.multiround - 1) + 16, 576, 1024) and torch.isfinite(video).all()
+        multi = {"rounds": a.multiround, "frames": int(video.shape[3]), "seconds": dtm,
+                 "sec_per_round": dtm / a.multiround, "resolution": "576x1024", "ddim_steps": 50, "n_gpus": 1,
+                 "includes": "AE encode of the conditioning frames + 50 CFG DDIM steps + AE decode of 16 frames per round"}
+
     if rank == 0:
         def roof(r):
             """the family with the largest measured share of the step"""
@@ -315,11 +367,18 @@ def main():
             b = r2["attn_big"]
             ach = b["flops"] / (b["ms"] * 1e-3) / 1e12
             out["roofline_attention"] = {
-                "bound": "mfma", "kernel": "pm_attention: spatial self-attention, N = 9216 tokens x 16 frames x 5 heads x "
-                                           "head dim 64 (576x1024, U-Net level 0), attn_self_kernel",
+                "bound": "mfma", "kernel": ("pm_attention_fp8 (attn_fp8_pack_kernel + attn_fp8_kernel, e4m3 on the block-scaled MFMA; "
+                                            "priced against the DENSE BF16 peak like the bf16 kernel: the fp8 dense peak is 2x)"
+                                            if a.fp8_attention else "pm_attention (attn_self_kernel)") +
+                                           ": spatial self-attention, N = 9216 tokens x 16 frames x 5 heads x head dim 64 "
+                                           "(576x1024, U-Net level 0)",
                 "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
                 "traffic": None, "launches": b["launches"], "avg_launch_ms": b["ms"] / b["launches"],
                 "flops_per_launch": b["flops"] / b["launches"]}
+        if a.fp8_attention:
+            out["config"]["attention"] = "fp8 (e4m3) operands on v_mfma_scale_f32_32x32x64_f8f6f4 for the spatial self-attention"
+        if multi is not None:
+            out["config4_multiround"] = multi
         if a.cpu_baseline == "auto" and world == 1:
             out["cpu_baseline"] = cpu_baseline(unet, res, head["ins"])
         print(json.dumps(out), flush=True)

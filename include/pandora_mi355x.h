@@ -186,6 +186,20 @@ int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const void* k1, cons
                  void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * pm_attention_fp8: single-segment softmax(q k^T * scale) v, head dim 64, with fp8 (OCP e4m3) q / k / v / P operands
+ * on the block-scaled MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, unit scales: K = 64 per instruction at twice the bf16
+ * rate), f32 accumulation and softmax statistics, 16-bit output.  BASELINE configs[4] ("fp8 MFMA attention") for the
+ * spatial self-attention call site attention.py:101-125; same addressing as pm_attention (k and v share strides).
+ * The call first packs q*scale*log2(e), k (fp8 rows) and v (fp8, transposed per head, keys in MFMA operand order) into
+ * `workspace` (pm_attention_fp8_workspace_bytes: 64 bytes per (batch, head, padded row) for each of q, k, v).
+ * Accuracy: e4m3 carries 3 mantissa bits - expect ~2-3e-2 norm-relative error per call (tests state the bound).
+ */
+size_t pm_attention_fp8_workspace_bytes(int64_t B, int64_t heads, int64_t Nq, int64_t Nk);
+int pm_attention_fp8(const void* q, int64_t q_bs, int64_t q_rs, const void* k, const void* v, int64_t k_bs,
+                     int64_t k_rs, int64_t Nk, void* o, int64_t o_bs, int64_t o_rs, int64_t B, int64_t heads,
+                     int64_t Nq, float scale, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * pm_attention_temporal: self-attention over the frame axis at every pixel (head dim 64).
  * replaces CrossAttention.forward as used by TemporalTransformer (attention.py:365-412; both attn1
  * and attn2 are self-attention over T because only_self_att=True, :347-348,389-390).

@@ -42,6 +42,10 @@ SIGNATURES = {
                              c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float,
                              c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int,
                              c_void_p]),
+    "pm_attention_fp8_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
+    "pm_attention_fp8": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                                 c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int, c_void_p, c_size_t,
+                                 c_void_p]),
     "pm_attention_temporal": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                       c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int,
                                       c_void_p]),

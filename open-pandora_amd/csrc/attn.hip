@@ -577,6 +577,299 @@ __global__ __launch_bounds__(256, (QB == 1 && RING == 2) ? 3 : 2) void attn_self
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp8 (OCP e4m3) attention on the block-scaled MFMA, v_mfma_scale_f32_32x32x64_f8f6f4 with unit scales: K = 64 per
+// instruction at twice the bf16 rate, so a 32-query x 64-key tile is 2 + 2 MFMAs of 64 cycles (256 matrix cycles)
+// instead of 8 + 8 of 32 (512), and every operand is 32 contiguous bytes per lane:
+//   S'^T = K . Q'^T - m   A = K tile rows [key][64 d] (lane: key = lane & 31, d = 32 (lane >> 5) .. + 31),
+//                         B = Q'^T from registers, C = the -m block (stale maximum, as attn_self_kernel);
+//   O^T += V^T . P^T      B = P^T: the S' accumulators ARE that operand once converted (v_cvt_pk_fp8_f32): a lane
+//                         holds, in register order, keys 8 g + 4 h + e (g = 0..7 dword, e byte, h = lane >> 5);
+//                         A = V^T tile rows [d][64 keys] whose keys are stored in exactly that order per lane half
+//                         (byte 32 h + 4 g + e of a row = key 8 g + 4 h + e): pm::attn_fp8_pack_kernel writes Q' and
+//                         K as fp8 rows and V transposed with that key permutation, once per call.
+// (The pairing of A and B elements inside the instruction is by (lane half, element index): any k order the two
+// operands share is legal - verified with exact integers by tools/probes/mfma_scale_fp8_layout.hip.)
+// LDS: K and V^T tiles are 64 rows x 64 bytes; the 16-byte chunk index is XOR-ed with (row >> 2) & 3 on the DMA's
+// source side, which makes the 2 x ds_read_b128 of a lane's 32 bytes conflict-free.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+struct AttnFp8Params {
+  const unsigned char* q8;   // [B*heads][Nq_pad][64]
+  const unsigned char* k8;   // [B*heads][Nk_pad][64]
+  const unsigned char* v8t;  // [B*heads][64][Nk_pad], keys permuted per 64-key tile
+  void* o;
+  int64_t o_bs, o_rs;
+  int Nq, Nk, Nq_pad, Nk_pad, heads, nqt;
+};
+
+constexpr int F8_TILE_BYTES = 64 * 64;  // one K or V^T tile
+constexpr float F8_STALE_THR = 4.0f;    // p <= 2^4 (e4m3 tops out at 448)
+
+__device__ __forceinline__ f32x16 mfma_f8(i32x8 a, i32x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127);  // fp8 x fp8, scales 2^0
+}
+
+template <typename T, int QB>
+__global__ __launch_bounds__(256, 2) void attn_fp8_kernel(const AttnFp8Params p) {
+  constexpr int RING = 2;
+  __shared__ __attribute__((aligned(16))) char smem[2 * RING * F8_TILE_BYTES];
+  char* const Ks = smem;
+  char* const Vs = smem + RING * F8_TILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, hh = lane >> 5;
+  int wg = blockIdx.x;
+  {
+    const int nwg = gridDim.x, qn = nwg >> 3, rn = nwg & 7, xcd = wg & 7;
+    wg = ((xcd < rn) ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (wg >> 3);
+  }
+  const int bh = wg / p.nqt;
+  const int qt = wg - bh * p.nqt;
+  const int b = bh / p.heads, head = bh - b * p.heads;
+
+  int qrow[QB];
+  bool q_valid[QB];
+  i32x8 qf[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    qrow[qb] = qt * (128 * QB) + wave * (32 * QB) + qb * 32 + ql;
+    q_valid[qb] = qrow[qb] < p.Nq;
+    if (!q_valid[qb]) qrow[qb] = p.Nq - 1;
+    const unsigned char* qp = p.q8 + ((int64_t)bh * p.Nq_pad + qrow[qb]) * 64 + 32 * hh;
+    const u32x4 lo = ld_global16(qp), hi = ld_global16(qp + 16);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      qf[qb][e] = (int)lo[e];
+      qf[qb][4 + e] = (int)hi[e];
+    }
+  }
+
+  const int Nk = p.Nk;
+  const int nkt = (Nk + KV_TILE - 1) / KV_TILE;
+  const char* const kbase = reinterpret_cast<const char*>(p.k8) + (int64_t)bh * p.Nk_pad * 64;
+  const char* const vbase = reinterpret_cast<const char*>(p.v8t) + (int64_t)bh * 64 * p.Nk_pad;
+  // DMA: lane t of wave w fills physical 16-byte chunk (t & 3) of tile row 16 w + (t >> 2)
+  const int lrow = 16 * wave + (lane >> 2);
+  const int lchunk = (lane & 3) ^ ((lrow >> 2) & 3);
+  const uint32_t koff = (uint32_t)(lrow * 64 + lchunk * 16);                      // + kt * 4096
+  const uint32_t voff = (uint32_t)lrow * (uint32_t)p.Nk_pad + (uint32_t)lchunk * 16;  // + kt * 64
+  auto load_kv = [&](int kt, int buf) {
+    const int dst = buf * F8_TILE_BYTES + wave * 1024;
+    __builtin_amdgcn_global_load_lds((glb_void*)(kbase + ((uint32_t)kt * 4096u + koff)), (lds_void*)(Ks + dst), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_void*)(vbase + ((uint32_t)kt * 64u + voff)), (lds_void*)(Vs + dst), 16, 0, 0);
+  };
+
+  f32x16 oacc[QB][2], nm[QB];
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    m_run[qb] = 0.f;
+    l_run[qb] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) nm[qb][r] = 0.f;
+    asm volatile("" : "+v"(nm[qb]));
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[qb][d][r] = 0.f;
+  }
+
+  // a lane's 32 operand bytes of tile row `row`: logical chunks 2 hh, 2 hh + 1
+  auto frag = [&](const char* tile, int row) -> i32x8 {
+    const int sw = (row >> 2) & 3;
+    const u32x4 lo = *reinterpret_cast<const u32x4*>(tile + row * 64 + (((2 * hh) ^ sw) << 4));
+    const u32x4 hi = *reinterpret_cast<const u32x4*>(tile + row * 64 + (((2 * hh + 1) ^ sw) << 4));
+    i32x8 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f[e] = (int)lo[e];
+      f[4 + e] = (int)hi[e];
+    }
+    return f;
+  };
+
+  auto raise = [&](int qb, f32x16 (&sacc)[2], float mx, bool first) {
+    float rmx = fmaxf(mx, other_half(mx));
+    if (!first) {
+      rmx = fmaxf(rmx, 0.f);
+      const float alpha = __builtin_amdgcn_exp2f(-rmx);
+      l_run[qb] *= alpha;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[qb][d][r] *= alpha;
+    }
+    m_run[qb] += rmx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) nm[qb][r] = -m_run[qb];
+    asm volatile("" : "+v"(nm[qb]));
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kb][r] -= rmx;
+  };
+
+  auto tile = [&](int kt, auto bufc, auto careful_c) {
+    constexpr bool CAREFUL = decltype(careful_c)::value;
+    const int buf = bufc;
+    const char* ks = Ks + buf * F8_TILE_BYTES;
+    const char* vs = Vs + buf * F8_TILE_BYTES;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      f32x16 sacc[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) sacc[kb] = mfma_f8(frag(ks, kb * 32 + ql), qf[qb], nm[qb]);
+      if constexpr (CAREFUL) {
+        if (kt * KV_TILE + KV_TILE > Nk) {
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = kt * KV_TILE + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+              if (key >= Nk) sacc[kb][r] = -INFINITY;
+            }
+        }
+      }
+      float m0 = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) m0 = fmaxf(fmaxf(m0, sacc[0][r]), sacc[1][r]);
+      if constexpr (CAREFUL) {
+        raise(qb, sacc, m0, kt == 0);
+      } else {
+        if (__builtin_amdgcn_ballot_w64(m0 > F8_STALE_THR) != 0) raise(qb, sacc, m0, false);
+      }
+      // p = 2^S', row sum (f32, unrounded), P^T operand in e4m3: dword g = keys 8 g' + 4 hh + (0..3)
+      float ps[4] = {0.f, 0.f, 0.f, 0.f};
+      i32x8 pf;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float e[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            e[j] = __builtin_amdgcn_exp2f(sacc[kb][4 * g + j]);
+            ps[j] += e[j];
+          }
+          int w = __builtin_amdgcn_cvt_pk_fp8_f32(e[0], e[1], 0, false);
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(e[2], e[3], w, true);
+          pf[kb * 4 + g] = w;
+        }
+      l_run[qb] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) oacc[qb][db] = mfma_f8(frag(vs, db * 32 + ql), pf, oacc[qb][db]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  auto arrive = [&](int t) {
+    __syncthreads();
+    if (t + 1 < nkt) load_kv(t + 1, (t + 1) & 1);
+  };
+  load_kv(0, 0);
+  const int last_full = (Nk % KV_TILE == 0) ? nkt : nkt - 1;
+  arrive(0);
+  tile(0, std::integral_constant<int, 0>{}, std::true_type{});
+  int kt = 1;
+  for (; kt + 1 < last_full; kt += 2) {
+    arrive(kt);
+    tile(kt, std::integral_constant<int, 1>{}, std::false_type{});
+    arrive(kt + 1);
+    tile(kt + 1, std::integral_constant<int, 0>{}, std::false_type{});
+  }
+  for (; kt < last_full; ++kt) {
+    arrive(kt);
+    tile(kt, kt & 1, std::false_type{});
+  }
+  if (nkt > 1 && last_full < nkt) {
+    arrive(nkt - 1);
+    tile(nkt - 1, (nkt - 1) & 1, std::true_type{});
+  }
+
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const float l_tot = l_run[qb] + other_half(l_run[qb]);
+    const float inv = 1.0f / l_tot;
+    if (q_valid[qb]) {
+      T* op = reinterpret_cast<T*>(p.o) + (int64_t)b * p.o_bs + (int64_t)qrow[qb] * p.o_rs + head * 64;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          Pack4<T> ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov.e[e] = from_f32<T>(oacc[qb][db][4 * g + e] * inv);
+          *reinterpret_cast<u32x2*>(op + db * 32 + 8 * g + 4 * hh) = ov.u;
+        }
+    }
+  }
+}
+
+// q (scaled), k -> fp8 rows; v -> fp8, transposed per (batch, head) with the per-tile key permutation the P^T operand
+// dictates.  grid (q tiles + k tiles, B * heads), block 256: thread t handles row t >> 2, 16 channels 16 (t & 3).
+struct AttnFp8PackParams {
+  const void *q, *k, *v;
+  int64_t q_bs, q_rs, k_bs, k_rs;
+  unsigned char *q8, *k8, *v8t;
+  int Nq, Nk, Nq_pad, Nk_pad, heads, ntq;
+  float qscale;
+};
+
+__device__ __forceinline__ float clamp_e4m3(float x) { return fminf(fmaxf(x, -448.f), 448.f); }
+
+template <typename T> __global__ __launch_bounds__(256) void attn_fp8_pack_kernel(const AttnFp8PackParams p) {
+  __shared__ unsigned char vt[64 * 64];
+  const int t = threadIdx.x, row = t >> 2, c16 = (t & 3) * 16;
+  const int bh = blockIdx.y, b = bh / p.heads, head = bh - b * p.heads;
+  const bool is_q = (int)blockIdx.x < p.ntq;
+  const int tile = is_q ? blockIdx.x : blockIdx.x - p.ntq;
+  const int n = tile * 64 + row;
+  const int N = is_q ? p.Nq : p.Nk;
+  auto load16 = [&](const void* base, int64_t bs, int64_t rs, float scale, float (&x)[16]) {
+    if (n < N) {
+      const T* src = reinterpret_cast<const T*>(base) + (int64_t)b * bs + (int64_t)n * rs + head * 64 + c16;
+      Pack8<T> a, c;
+      a.u = ld_global16(src);
+      c.u = ld_global16(src + 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        x[e] = clamp_e4m3(to_f32(a.e[e]) * scale);
+        x[8 + e] = clamp_e4m3(to_f32(c.e[e]) * scale);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) x[e] = 0.f;
+    }
+  };
+  auto pack16 = [&](const float (&x)[16]) -> u32x4 {
+    u32x4 w;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      int v = __builtin_amdgcn_cvt_pk_fp8_f32(x[4 * g], x[4 * g + 1], 0, false);
+      v = __builtin_amdgcn_cvt_pk_fp8_f32(x[4 * g + 2], x[4 * g + 3], v, true);
+      w[g] = (unsigned)v;
+    }
+    return w;
+  };
+  float x[16];
+  if (is_q) {
+    load16(p.q, p.q_bs, p.q_rs, p.qscale, x);
+    st_global16(p.q8 + ((int64_t)bh * p.Nq_pad + n) * 64 + c16, pack16(x));
+    return;
+  }
+  load16(p.k, p.k_bs, p.k_rs, 1.f, x);
+  st_global16(p.k8 + ((int64_t)bh * p.Nk_pad + n) * 64 + c16, pack16(x));
+  load16(p.v, p.k_bs, p.k_rs, 1.f, x);
+  const u32x4 vw = pack16(x);
+  // transpose through LDS: byte of (d, key = row) goes to vt[d][pos(key)], pos = 32 h + 4 g + e for key = 8 g + 4 h + e
+  const int pos = 32 * ((row >> 2) & 1) + 4 * (row >> 3) + (row & 3);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) vt[(c16 + e) * 64 + pos] = (unsigned char)(vw[e >> 2] >> (8 * (e & 3)));
+  __syncthreads();
+  const u32x4 o = *reinterpret_cast<const u32x4*>(vt + row * 64 + c16);  // row = d, 16 permuted keys
+  st_global16(p.v8t + ((int64_t)bh * 64 + row) * p.Nk_pad + tile * 64 + c16, o);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Temporal self-attention: at every (pixel, head) a (Fq x Fk <= 16 x 16) attention over the frame
 // axis, head dim 64.  HBM-bound (0.1 % of the FLOPs) - the job is to touch q, k, v, o once with wide
 // loads and keep the arithmetic off the VALU:
@@ -749,6 +1042,43 @@ extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const voi
   if (variant == 5) PM_ATTN_LAUNCH(2, true, true, 4);
   PM_ATTN_LAUNCH(1, false, false, 2);
 #undef PM_ATTN_LAUNCH
+}
+
+extern "C" size_t pm_attention_fp8_workspace_bytes(int64_t B, int64_t heads, int64_t Nq, int64_t Nk) {
+  const int64_t nq = (Nq + 63) / 64 * 64, nk = (Nk + 63) / 64 * 64;
+  return (size_t)(B * heads * 64 * (nq + 2 * nk));
+}
+
+extern "C" int pm_attention_fp8(const void* q, int64_t q_bs, int64_t q_rs, const void* k, const void* v,
+                                int64_t k_bs, int64_t k_rs, int64_t Nk, void* o, int64_t o_bs, int64_t o_rs,
+                                int64_t B, int64_t heads, int64_t Nq, float scale, int dtype, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  if (!q || !k || !v || !o || !workspace) return PM_E_NULL;
+  if (B < 1 || heads < 1 || Nq < 1 || Nk < 1) return PM_E_SHAPE;
+  if ((q_bs | q_rs | k_bs | k_rs | o_bs | o_rs) & 7) return PM_E_SHAPE;
+  if (workspace_bytes < pm_attention_fp8_workspace_bytes(B, heads, Nq, Nk)) return PM_E_WORKSPACE;
+  const int64_t nq = (Nq + 63) / 64 * 64, nk = (Nk + 63) / 64 * 64;
+  if (nk * 64 >= (1ll << 31) || B * heads > 65535) return PM_E_SHAPE;
+  unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
+  AttnFp8PackParams pp{};
+  pp.q = q; pp.k = k; pp.v = v; pp.q_bs = q_bs; pp.q_rs = q_rs; pp.k_bs = k_bs; pp.k_rs = k_rs;
+  pp.q8 = ws; pp.k8 = ws + B * heads * nq * 64; pp.v8t = pp.k8 + B * heads * nk * 64;
+  pp.Nq = (int)Nq; pp.Nk = (int)Nk; pp.Nq_pad = (int)nq; pp.Nk_pad = (int)nk; pp.heads = (int)heads;
+  pp.ntq = (int)(nq / 64);
+  pp.qscale = scale * 1.4426950408889634f;  // scores in the base-2 domain
+  dim3 pgrid((unsigned)(nq / 64 + nk / 64), (unsigned)(B * heads));
+  AttnFp8Params p{};
+  p.q8 = pp.q8; p.k8 = pp.k8; p.v8t = pp.v8t; p.o = o; p.o_bs = o_bs; p.o_rs = o_rs;
+  p.Nq = (int)Nq; p.Nk = (int)Nk; p.Nq_pad = (int)nq; p.Nk_pad = (int)nk; p.heads = (int)heads;
+  const bool qb2 = g_attn_variant == 2 || (g_attn_variant == 0 && ((Nq + 255) / 256) * B * heads >= 512);
+  const int rows = qb2 ? 256 : 128;
+  p.nqt = (int)((Nq + rows - 1) / rows);
+  dim3 grid((unsigned)(p.nqt * B * heads));
+  PM_DISPATCH_DTYPE(dtype, T,
+                    hipLaunchKernelGGL((attn_fp8_pack_kernel<T>), pgrid, dim3(256), 0, (hipStream_t)stream, pp);
+                    if (qb2) hipLaunchKernelGGL((attn_fp8_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
+                    else hipLaunchKernelGGL((attn_fp8_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);
+                    return check_launch());
 }
 
 extern "C" int pm_attention_temporal(const void* q, int64_t ldq, const void* k, const void* v,

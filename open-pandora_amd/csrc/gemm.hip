@@ -82,14 +82,22 @@ __device__ __forceinline__ int cperm(int pr, bool geglu) {
 // bias of this lane's 16 output columns, bv[j][r] <-> column block j, column 4*fq + r in MFMA order
 __device__ __forceinline__ void load_bias_regs(const GemmParams& p, float (&bv)[4][4], int n0, int wn, int fq) {
   const float* bias_p = (p.splits > 1) ? nullptr : p.bias;
+  const bool geglu = p.act == PM_ACT_GEGLU;
+  // column of element (j, 0): the 4 elements r = 0..3 are consecutive columns -> one 16-byte load per j when the
+  // run lies inside [0, N) (N % 4 == 0 on every shape of the path); clamped address + select otherwise
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < 4; ++j) {
+    const int n = geglu ? n0 + wn * 64 + j * 16 + 4 * fq : n0 + wn * 64 + (j >> 1) * 32 + fq * 8 + (j & 1) * 4;
+    if (bias_p != nullptr && (p.N & 3) == 0) {
+      const bool ok = n + 4 <= p.N;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(bias_p + (ok ? n : 0));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = (p.act == PM_ACT_GEGLU) ? n0 + wn * 64 + j * 16 + 4 * fq + r
-                                            : n0 + wn * 64 + (j >> 1) * 32 + fq * 8 + (j & 1) * 4 + r;
-      bv[j][r] = (bias_p != nullptr && n < p.N) ? bias_p[n] : 0.f;
+      for (int r = 0; r < 4; ++r) bv[j][r] = ok ? t[r] : 0.f;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[j][r] = (bias_p != nullptr && n + r < p.N) ? bias_p[n + r] : 0.f;
     }
+  }
 }
 // Straight-line store pass of one epilogue flavour (OUT32: f32 output; RES: 0 none, 1 16-bit, 2 f32 residual).
 // The generic epilogue below carries every flavour behind runtime branches, replicated 8x by the unrolled
@@ -738,10 +746,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   int w = xcd_remap(blockIdx.x, G);  // (G <= nwork: every workgroup has a first item)
   int buf = 0;
   load_tile(loader_begin(w), 0);
+  // The residual (accumulator start values) and the bias of the FIRST tile are requested right behind its first
+  // K-tile's DMA and before the barrier that waits for it: their round trips overlap.  They used to be issued after
+  // that barrier and waited for on their own - two memory latencies in a row at the head of every workgroup, as
+  // long as the whole K loop of a K = 320 GEMM.
+  f32x4 acc[4][4];
+  float bv[4][4];
+  bool res_done;
+  {
+    int mt, nt, split;
+    decode(w, mt, nt, split);
+    res_done = residual_into_acc<T>(p, acc, mt * BMT, nt * BN, wm, wn, fr, fq);
+    load_bias_regs(p, bv, nt * BN, wn, fq);
+  }
   store_tile(0);
   __syncthreads();  // (hipcc drains vmcnt before the barrier, so the DMA'd tile is visible)
 
-  for (;;) {
+  for (bool first_item = true;; first_item = false) {
     int mt, nt, split;
     decode(w, mt, nt, split);
     const int m0 = mt * BMT, n0 = nt * BN;
@@ -749,16 +770,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     const int kt1 = (kt0 + p.ktps < nk_all) ? kt0 + p.ktps : nk_all;
     const bool has_next = PERSIST && (w + G < nwork);
 
-    f32x4 acc[4][4];
-    const bool res_done = residual_into_acc<T>(p, acc, m0, n0, wm, wn, fr, fq);
+    if (!first_item) {
+      res_done = residual_into_acc<T>(p, acc, m0, n0, wm, wn, fr, fq);
+      load_bias_regs(p, bv, n0, wn, fq);  // requested now, needed in the epilogue
+    }
     if (!res_done) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    float bv[4][4];  // bias of this lane's columns: requested now, needed in the epilogue
-    load_bias_regs(p, bv, n0, wn, fq);
 
     for (int kt = kt0; kt < kt1; ++kt) {
       const bool more = (kt + 1 < kt1) || has_next;

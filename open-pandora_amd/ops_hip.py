@@ -28,10 +28,12 @@ class HipOps:
     # attention(..., prescaled=True); otherwise the kernel scales (and re-rounds) the q fragments itself.
     q_prescale = 64 ** -0.5 * 1.4426950408889634
 
-    def __init__(self, dtype=torch.bfloat16, device="cuda", workspace_mb=256):
+    def __init__(self, dtype=torch.bfloat16, device="cuda", workspace_mb=256, fp8_attention=False):
         if dtype not in _DT:
             raise ValueError(f"HipOps supports float16/bfloat16 activations, got {dtype}")
         self.lib = capi.load()
+        # BASELINE configs[4]: the spatial self-attention of the U-Net on pm_attention_fp8 (opt-in: ~2-3e-2 per call)
+        self.fp8_attention = bool(fp8_attention)
         if os.environ.get("PANDORA_Q_PRESCALE", "1") == "0":  # (numerics experiments: scale inside the kernel)
             self.q_prescale = None
         self.dtype = dtype
@@ -283,6 +285,27 @@ class HipOps:
                                    out.stride(0), out.stride(1), B, heads, Nq, scale, self.dt,
                                    self._stream())
         capi.check(rc, f"pm_attention B={B} heads={heads} Nq={Nq} Nk={n1}+{n2}")
+        return out
+
+    def attention_fp8(self, q, k, v, heads, out=None, prescaled=False):
+        """Single-segment attention with fp8 (e4m3) operands on the block-scaled MFMA (pm_attention_fp8): q [B, Nq, C],
+        k / v [B, Nk, C] views of identical strides.  ~2-3e-2 relative error: BASELINE configs[4], opt-in."""
+        B, Nq, C = q.shape
+        Nk = k.shape[1]
+        assert C == heads * 64 and q.stride(2) == 1 and k.stride(2) == 1 and k.shape == v.shape and k.stride() == v.stride()
+        assert k.shape[0] == B and q.dtype == self.dtype
+        if out is None:
+            out = self.empty(B, Nq, C)
+        need = self.lib.pm_attention_fp8_workspace_bytes(B, heads, Nq, Nk)
+        key = ("fp8", self._stream())
+        ws = self._workspaces.get(key)
+        if ws is None or ws.numel() < need:
+            ws = self._workspaces[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        scale = math.log(2.0) if prescaled else 64 ** -0.5
+        rc = self.lib.pm_attention_fp8(_ptr(q), q.stride(0), q.stride(1), _ptr(k), _ptr(v), k.stride(0), k.stride(1), Nk,
+                                       _ptr(out), out.stride(0), out.stride(1), B, heads, Nq, scale, self.dt,
+                                       _ptr(ws), ws.numel(), self._stream())
+        capi.check(rc, f"pm_attention_fp8 B={B} heads={heads} Nq={Nq} Nk={Nk}")
         return out
 
     def attention_temporal(self, q, k, v, heads, out=None):

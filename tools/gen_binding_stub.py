@@ -34,5 +34,17 @@ def stub():
     return "\n".join(out)
 
 
+def write_doc():
+    """replace the generated block of INTEGRATION.md in place"""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")
+    doc = open(path).read()
+    head, rest = doc.split("<!-- BEGIN GENERATED STUB -->\n```python\n")
+    tail = rest.split("\n```\n<!-- END GENERATED STUB -->")[1]
+    open(path, "w").write(head + "<!-- BEGIN GENERATED STUB -->\n```python\n" + stub() + "\n```\n<!-- END GENERATED STUB -->" + tail)
+
+
 if __name__ == "__main__":
-    print(stub())
+    if "--write" in sys.argv:
+        write_doc()
+    else:
+        print(stub())
