@@ -1038,7 +1038,6 @@ extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const voi
                       hipLaunchKernelGGL((attn_kernel<T, 1, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
                       return check_launch());
   if (variant == 3) PM_ATTN_LAUNCH(2, true, false, 4);
-  if (variant == 4) PM_ATTN_LAUNCH(1, false, true, 2);
   if (variant == 5) PM_ATTN_LAUNCH(2, true, true, 4);
   PM_ATTN_LAUNCH(1, false, false, 2);
 #undef PM_ATTN_LAUNCH
@@ -1070,7 +1069,7 @@ extern "C" int pm_attention_fp8(const void* q, int64_t q_bs, int64_t q_rs, const
   AttnFp8Params p{};
   p.q8 = pp.q8; p.k8 = pp.k8; p.v8t = pp.v8t; p.o = o; p.o_bs = o_bs; p.o_rs = o_rs;
   p.Nq = (int)Nq; p.Nk = (int)Nk; p.Nq_pad = (int)nq; p.Nk_pad = (int)nk; p.heads = (int)heads;
-  const bool qb2 = g_attn_variant == 2 || (g_attn_variant == 0 && ((Nq + 255) / 256) * B * heads >= 512);
+  const bool qb2 = g_attn_variant == 2;  // (32 rows per wave measured faster at every N: tools/attn_bench.py 101 / 102)
   const int rows = qb2 ? 256 : 128;
   p.nqt = (int)((Nq + rows - 1) / rows);
   dim3 grid((unsigned)(p.nqt * B * heads));

@@ -28,12 +28,13 @@ class HipOps:
     # attention(..., prescaled=True); otherwise the kernel scales (and re-rounds) the q fragments itself.
     q_prescale = 64 ** -0.5 * 1.4426950408889634
 
-    def __init__(self, dtype=torch.bfloat16, device="cuda", workspace_mb=256, fp8_attention=False):
+    def __init__(self, dtype=torch.bfloat16, device="cuda", workspace_mb=256, fp8_attention=False, fp8_min_tokens=2048):
         if dtype not in _DT:
             raise ValueError(f"HipOps supports float16/bfloat16 activations, got {dtype}")
         self.lib = capi.load()
         # BASELINE configs[4]: the spatial self-attention of the U-Net on pm_attention_fp8 (opt-in: ~2-3e-2 per call)
         self.fp8_attention = bool(fp8_attention)
+        self.fp8_min_tokens = int(fp8_min_tokens)  # shorter sequences stay on pm_attention (the packing pass costs more than it saves)
         if os.environ.get("PANDORA_Q_PRESCALE", "1") == "0":  # (numerics experiments: scale inside the kernel)
             self.q_prescale = None
         self.dtype = dtype

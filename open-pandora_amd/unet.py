@@ -456,7 +456,7 @@ class UNetModel(packing.PackedWeights, nn.Module):
                     if gather:  # frame-sharded without the pixel re-shard: all-gather K|V over frames
                         k, v = c.fp.gather_kv(qkv, inner, P)
                     a = ops.attention_temporal(q, k, v, heads)
-                elif getattr(ops, "fp8_attention", False):
+                elif getattr(ops, "fp8_attention", False) and P >= ops.fp8_min_tokens:
                     a = ops.attention_fp8(q, k, v, heads, prescaled=qs is not None)
                 elif qs is not None:
                     a = ops.attention(q, k, v, heads, prescaled=True)

@@ -488,7 +488,7 @@ def _attn_ref_base2(q, k, v, heads):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("variant", [1, 3, 4, 5])
+@pytest.mark.parametrize("variant", [1, 3, 5])
 def test_attention_stale_max_paths(hip_ops_factory, dtype, variant):
     """attn_self_kernel keeps a STALE running maximum that is only raised when a tile outgrows it by 2^6: force
     every branch (cdna guide rule 26) - a raise in a fast (unmasked, not first) tile, twice for the same row; a

@@ -59,7 +59,7 @@ def test_unet_small_forward_fp8_attention(tag, mc, h, w, t, fs):
     """The opt-in fp8 attention of configs[4] inside the U-Net: its own, separately stated tolerance."""
     from open_pandora_amd.ops_hip import HipOps
     g = load("unet_small.npz")[tag]
-    m = small_model(mc, HipOps(torch.float16, "cuda:0", fp8_attention=True))
+    m = small_model(mc, HipOps(torch.float16, "cuda:0", fp8_attention=True, fp8_min_tokens=0))
     ins, _, _ = gr.sampler_inputs(h, w)
     x = torch.cat([ins["x_T"], ins["c_concat"]], 1).cuda()
     y = m(x, torch.tensor([t]).cuda(), context=ins["c_crossattn"].cuda(), fs=torch.tensor([fs]).cuda())

@@ -16,7 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--variants", default="9,1,3,4,5")
+    ap.add_argument("--variants", default="9,1,3,5,101")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     ops = HipOps(dt, "cuda:0")

@@ -1,0 +1,36 @@
+#!/bin/bash
+# Collect the round's measurement artefacts on the GPU box into gpurun_out/$1 (copy what is to be judged into
+# profiles/$1 afterwards).  usage: tools/collect_profiles.sh r02
+set -u
+R=${1:-r02}; O=gpurun_out/$R; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+PMC_SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
+# 1. the driver's command, plain and under rocprofv3 --kernel-trace --stats
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_trace -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-baseline off > $O/bench_under_rocprof.json 2>/dev/null
+cp $O/bench_trace/*/*kernel_stats.csv $O/bench_kernel_stats.csv
+# 2. per-forward kernel breakdown (difference of two graph-free runs) at both resolutions
+for res in 320x512 576x1024; do
+  for n in 2 6; do
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/fwd_${res}_$n -- python3 tools/fwd_only.py $n $res > /dev/null 2>&1
+  done
+  python3 tools/diff_stats.py $O/fwd_${res}_2/*/*kernel_stats.csv 2 $O/fwd_${res}_6/*/*kernel_stats.csv 6 > $O/forward_kernel_breakdown_$res.txt
+  python3 tools/shape_profile.py --res $res --reps 3 > $O/per_shape_table_$res.txt 2>/dev/null
+done
+# 3. counters of the dominant kernels: SQ set, then FETCH_SIZE and WRITE_SIZE in passes of their own
+rocprofv3 --kernel-trace --pmc $PMC_SQ --output-format csv -d $O/pmc_sq -- python3 tools/gemm_probe.py > /dev/null 2>&1
+python3 tools/pmc_table.py $O/pmc_sq > $O/pmc_sq.txt
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 tools/gemm_probe.py > /dev/null 2>&1
+python3 tools/pmc_table.py $O/pmc_fetch > $O/pmc_fetch.txt
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 tools/gemm_probe.py > /dev/null 2>&1
+python3 tools/pmc_table.py $O/pmc_write > $O/pmc_write.txt
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_calib -- python3 tools/fetch_calib.py > $O/fetch_calib.txt 2>/dev/null
+python3 tools/pmc_table.py $O/pmc_calib >> $O/fetch_calib.txt
+# 4. attention A/B (bf16 variants + fp8) and its SQ counters
+python3 tools/attn_bench.py --rounds 7 --variants 9,1,3,5,101 > $O/attention_ab.txt 2>/dev/null
+rocprofv3 --kernel-trace --pmc $PMC_SQ --output-format csv -d $O/pmc_attn -- python3 tools/attn_pmc.py > /dev/null 2>&1
+python3 tools/pmc_table.py $O/pmc_attn > $O/pmc_attention_n9216.txt
+# 5. configs[2] alone, configs[4] (fp8 attention, 5 rounds)
+python3 bench.py --steps 10 --warmup 3 --cpu-baseline off --fp8-attention --multiround 5 > $O/bench_fp8_multiround.json 2>/dev/null
+rm -rf $O/bench_trace $O/fwd_* $O/pmc_sq $O/pmc_fetch $O/pmc_write $O/pmc_calib $O/pmc_attn
+ls -la $O

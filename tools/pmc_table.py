@@ -19,9 +19,10 @@ for f in cc:
         name = r["Kernel_Name"]
         if "pm" not in name:
             continue
-        d[name[:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        key = name[:70] + "  grid=" + r.get("Grid_Size", "?")
+        d[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
         if r["Dispatch_Id"] in dur:
-            d[name[:70]]["_dur_s"].append(dur[r["Dispatch_Id"]])
+            d[key]["_dur_s"].append(dur[r["Dispatch_Id"]])
 for k, v in d.items():
     avg = {c: sum(x) / len(x) for c, x in v.items()}
     line = k + "\n   " + "  ".join(f"{c}={a:.4g}" for c, a in sorted(avg.items()))
