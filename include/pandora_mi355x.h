@@ -200,6 +200,16 @@ int pm_attention_fp8(const void* q, int64_t q_bs, int64_t q_rs, const void* k, c
                      int64_t Nq, float scale, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * pm_attention_generic: softmax(q k^T * scale) v for ANY head dim D <= 128 (D % 8 == 0) and Nk <= 1024, f32
+ * arithmetic, single key/value segment.  For the OpenCLIP ViT-H/14 image tower of the conditioning tail
+ * (nn.MultiheadAttention with 16 heads of 80 channels over 257 tokens, condition.py:300-382, once per generate call);
+ * element (b, i, h, d) at base + b*bs + i*rs + h*D + d as in pm_attention (k and v share strides).
+ */
+int pm_attention_generic(const void* q, int64_t q_bs, int64_t q_rs, const void* k, const void* v, int64_t k_bs,
+                         int64_t k_rs, int64_t Nk, void* o, int64_t o_bs, int64_t o_rs, int64_t B, int64_t heads,
+                         int64_t Nq, int64_t D, float scale, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * pm_attention_temporal: self-attention over the frame axis at every pixel (head dim 64).
  * replaces CrossAttention.forward as used by TemporalTransformer (attention.py:365-412; both attn1
  * and attn2 are self-attention over T because only_self_att=True, :347-348,389-390).

@@ -46,6 +46,8 @@ SIGNATURES = {
     "pm_attention_fp8": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p,
                                  c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int, c_void_p, c_size_t,
                                  c_void_p]),
+    "pm_attention_generic": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                                     c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int, c_void_p]),
     "pm_attention_temporal": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                       c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int,
                                       c_void_p]),

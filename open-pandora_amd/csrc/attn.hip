@@ -983,6 +983,90 @@ __global__ __launch_bounds__(256) void tattn_kernel(const TAttnParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small generic attention: any head dim D <= 128 (D % 8 == 0), Nk <= 1024, f32 arithmetic on the vector ALU.
+// For the OpenCLIP ViT-H/14 image tower of the conditioning tail (condition.py:300-382: 257 tokens, 16 heads of
+// 80 channels, 32 layers, once per generate call - 5 GFLOP in all): the MFMA kernels above are specialised for head
+// dim 64.  One wave per query row: lanes own keys (scores: q from registers, K rows from L2), wave-wide max / sum,
+// probabilities through a 4 KiB LDS row, then lanes own output channels (V rows read coalesced).
+struct AttnSmallParams {
+  const void *q, *k, *v;
+  void* o;
+  int64_t q_bs, q_rs, k_bs, k_rs, o_bs, o_rs;
+  int Nq, Nk, heads, D;
+  float scale;
+};
+
+template <typename T> __global__ __launch_bounds__(256) void attn_small_kernel(const AttnSmallParams p) {
+  __shared__ float prob[4][1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bh = blockIdx.y, b = bh / p.heads, head = bh - b * p.heads;
+  const int qi = blockIdx.x * 4 + wave;
+  if (qi >= p.Nq) return;  // (wave-uniform; no block-wide barrier below)
+  const int D = p.D, nv = D >> 3;
+  const T* qp = reinterpret_cast<const T*>(p.q) + (int64_t)b * p.q_bs + (int64_t)qi * p.q_rs + head * D;
+  const T* kb = reinterpret_cast<const T*>(p.k) + (int64_t)b * p.k_bs + head * D;
+  const T* vb = reinterpret_cast<const T*>(p.v) + (int64_t)b * p.k_bs + head * D;
+  float qv[128];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    if (c < nv) {
+      Pack8<T> t;
+      t.u = ld_global16(qp + 8 * c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qv[8 * c + e] = to_f32(t.e[e]) * p.scale;
+    }
+  }
+  float sc[16];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int j = lane + 64 * t;
+    sc[t] = -INFINITY;
+    if (j < p.Nk) {
+      const T* kr = kb + (int64_t)j * p.k_rs;
+      float a = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        if (c < nv) {
+          Pack8<T> kk;
+          kk.u = ld_global16(kr + 8 * c);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a = fmaf(qv[8 * c + e], to_f32(kk.e[e]), a);
+        }
+      }
+      sc[t] = a;
+      mx = fmaxf(mx, a);
+    }
+  }
+  mx = wave_max(mx);
+  float l = 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int j = lane + 64 * t;
+    if (j < p.Nk) {
+      const float e = __expf(sc[t] - mx);
+      l += e;
+      prob[wave][j] = e;
+    }
+  }
+  l = wave_sum(l);
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes are done (wave-private row: no barrier)
+  const float inv = 1.0f / l;
+  // output channels d = lane and lane + 64
+  float o0 = 0.f, o1 = 0.f;
+  const bool h0 = lane < D, h1 = lane + 64 < D;
+  for (int j = 0; j < p.Nk; ++j) {
+    const float pj = prob[wave][j];
+    const T* vr = vb + (int64_t)j * p.k_rs;
+    if (h0) o0 = fmaf(pj, to_f32(vr[lane]), o0);
+    if (h1) o1 = fmaf(pj, to_f32(vr[lane + 64]), o1);
+  }
+  T* op = reinterpret_cast<T*>(p.o) + (int64_t)b * p.o_bs + (int64_t)qi * p.o_rs + head * D;
+  if (h0) op[lane] = from_f32<T>(o0 * inv);
+  if (h1) op[lane + 64] = from_f32<T>(o1 * inv);
+}
+
 }  // namespace pm
 
 using namespace pm;
@@ -1077,6 +1161,23 @@ extern "C" int pm_attention_fp8(const void* q, int64_t q_bs, int64_t q_rs, const
                     hipLaunchKernelGGL((attn_fp8_pack_kernel<T>), pgrid, dim3(256), 0, (hipStream_t)stream, pp);
                     if (qb2) hipLaunchKernelGGL((attn_fp8_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
                     else hipLaunchKernelGGL((attn_fp8_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);
+                    return check_launch());
+}
+
+extern "C" int pm_attention_generic(const void* q, int64_t q_bs, int64_t q_rs, const void* k, const void* v,
+                                    int64_t k_bs, int64_t k_rs, int64_t Nk, void* o, int64_t o_bs, int64_t o_rs,
+                                    int64_t B, int64_t heads, int64_t Nq, int64_t D, float scale, int dtype,
+                                    void* stream) {
+  if (!q || !k || !v || !o) return PM_E_NULL;
+  if (B < 1 || heads < 1 || Nq < 1 || Nk < 1 || Nk > 1024 || D < 8 || D > 128 || (D & 7)) return PM_E_SHAPE;
+  if ((q_bs | q_rs | k_bs | k_rs | o_bs | o_rs) & 7) return PM_E_SHAPE;
+  if (B * heads > 65535) return PM_E_SHAPE;
+  AttnSmallParams p{};
+  p.q = q; p.k = k; p.v = v; p.o = o; p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs;
+  p.o_bs = o_bs; p.o_rs = o_rs; p.Nq = (int)Nq; p.Nk = (int)Nk; p.heads = (int)heads; p.D = (int)D; p.scale = scale;
+  dim3 grid((unsigned)((Nq + 3) / 4), (unsigned)(B * heads));
+  PM_DISPATCH_DTYPE(dtype, T,
+                    hipLaunchKernelGGL((attn_small_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, p);
                     return check_launch());
 }
 

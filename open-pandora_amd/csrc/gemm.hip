@@ -477,10 +477,12 @@ template <typename T, int AMODE, bool A32>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   typedef typename std::conditional<A32, float, T>::type TA;  // storage type of the A operand
   constexpr int ES = sizeof(TA);
-  // Persistent walk (several work items per workgroup, the next item's first K-tile issued before this
-  // item's epilogue): measured no gain over one item per workgroup, and the extra live state pushed the
-  // f32-operand instantiations past 256 VGPRs, so it is compiled out.
-  constexpr bool PERSIST = false;
+  // Persistent walk (16-bit operands): a workgroup takes work items w, w + G, ...; the next item's first K-tile is
+  // issued in the last K-step of this item and its barrier is deferred to BEHIND the epilogue (the epilogue is
+  // LDS-free), so that DMA round trip and the next tile's residual / bias loads fly during the stores instead of
+  // at the head of a fresh workgroup.  (The f32-operand instantiations stay one item per workgroup: the extra live
+  // state pushed them past 256 VGPRs.)
+  constexpr bool PERSIST = !A32;
   constexpr int NT = 256;                    // threads
   constexpr int WMW = 2;                     // waves along M (2 along N)
   constexpr int BMT = WMW * 64;              // tile rows
@@ -809,7 +811,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
           for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(b[ks][j].v, a[ks][i].v, acc[i][j]);  // C^T: see epilogue_regs
       }
       if (more) store_tile(buf ^ 1);
-      __syncthreads();
+      if (kt + 1 < kt1 || !has_next) __syncthreads();  // (last step before a prefetched item: barrier after the epilogue)
       buf ^= 1;
     }
     // ---------------- epilogue: registers -> global (no LDS staging, no barrier) ----------------
@@ -817,6 +819,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     epilogue_regs<T>(p, acc, bv, m0, n0, wm, wn, fr, fq, mt * WMW + wm, split, res_done);
     if (!has_next) break;
     w += G;
+    __syncthreads();  // the prefetched first K-tile of item w has landed (vmcnt drained here, behind the stores)
   }
 }
 
@@ -1343,6 +1346,7 @@ constexpr int MAX_DEVICES = 64;
 static int g_ring = 1;  // PANDORA_GEMM_RING: 0 = never, 1 = by prefer_ring(), 2 = always
 static int g_ring_max_work = 0;  // PANDORA_GEMM_RING_MAX_WORK > 0: never use the ring kernel above that many work items
 static int g_num_cus[MAX_DEVICES] = {0};
+static int g_persist_per_cu = 0;    // PANDORA_GEMM_PERSIST: persistent 2-stage workgroups per CU (0 = one work item per workgroup; measured: 2/CU = no gain, 1 or 3/CU 5 % slower)
 static int g_split_min_nk = 24;     // PANDORA_SPLITK_MIN_NK: shortest K loop (in 64-wide tiles) that is split
 
 static int current_device() {
@@ -1362,6 +1366,8 @@ static void init_once() {
     if (r) g_ring = atoi(r);
     const char* rw = getenv("PANDORA_GEMM_RING_MAX_WORK");
     if (rw) g_ring_max_work = atoi(rw);
+    const char* ps = getenv("PANDORA_GEMM_PERSIST");
+    if (ps) g_persist_per_cu = atoi(ps);
     return true;
   }();
   (void)init;
@@ -1428,7 +1434,9 @@ template <typename T, int AMODE, bool A32> static int launch1(const GemmParams& 
   GemmParams q = p;
   q.mtiles = (p.M + BM - 1) / BM;
   const int64_t nwork = (int64_t)q.mtiles * p.ntiles * p.splits;
-  const int grid = (int)nwork;  // one work item per workgroup (see PERSIST in the kernel)
+  // 16-bit operands: persistent walk, up to g_persist_wgs workgroups per CU's worth of slots; f32 A: one item each
+  const int64_t cap = (int64_t)g_persist_per_cu * num_cus();
+  const int grid = (int)((A32 || g_persist_per_cu <= 0 || nwork <= cap) ? nwork : cap);
   static bool attr_set[MAX_DEVICES] = {false};  // per device; idempotent (a benign race sets the same value twice)
   const int dev = current_device();
   if (!attr_set[dev]) {

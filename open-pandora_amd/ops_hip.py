@@ -309,6 +309,19 @@ class HipOps:
         capi.check(rc, f"pm_attention_fp8 B={B} heads={heads} Nq={Nq} Nk={Nk}")
         return out
 
+    def attention_generic(self, q, k, v, heads, out=None):
+        """Any head dim <= 128 (pm_attention_generic): q [B, Nq, heads*D], k / v [B, Nk, heads*D] views, Nk <= 1024."""
+        B, Nq, C = q.shape
+        D = C // heads
+        assert D * heads == C and q.stride(2) == 1 and k.stride(2) == 1 and k.shape == v.shape and k.stride() == v.stride()
+        if out is None:
+            out = self.empty(B, Nq, C)
+        rc = self.lib.pm_attention_generic(_ptr(q), q.stride(0), q.stride(1), _ptr(k), _ptr(v), k.stride(0), k.stride(1),
+                                           k.shape[1], _ptr(out), out.stride(0), out.stride(1), B, heads, Nq, D,
+                                           float(D) ** -0.5, self.dt, self._stream())
+        capi.check(rc, f"pm_attention_generic B={B} heads={heads} Nq={Nq} D={D}")
+        return out
+
     def attention_temporal(self, q, k, v, heads, out=None):
         """q [Fq, P, heads*64], k/v [Fk, P, heads*64] views: attention over frames at each pixel."""
         Fq, P, C = q.shape

@@ -180,6 +180,13 @@ class TorchOps:
             y = y + w2 * self._attn(_f(q), _f(k2), _f(v2), heads)
         return self._out(y, out)
 
+    def attention_generic(self, q, k, v, heads, out=None):
+        B, Nq, C = q.shape
+        D = C // heads
+        sp = lambda t: _f(t).reshape(t.shape[0], t.shape[1], heads, D).permute(0, 2, 1, 3)
+        w = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * D ** -0.5, -1)
+        return self._out((w @ sp(v)).permute(0, 2, 1, 3).reshape(B, Nq, C), out)
+
     def attention_temporal(self, q, k, v, heads, out=None):
         # (Fq, P, C) -> batch over pixels: (P, Fq, C)
         y = self._attn(_f(q).permute(1, 0, 2), _f(k).permute(1, 0, 2), _f(v).permute(1, 0, 2), heads)

@@ -572,6 +572,19 @@ def test_attention_fp8_exact_on_fp8_representable_inputs(hip_ops_factory):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,heads,D,Nq,Nk", [(2, 16, 80, 257, 257), (1, 3, 128, 5, 1000), (3, 2, 8, 70, 64)])
+def test_attention_generic_head_dims(hip_ops_factory, dtype, B, heads, D, Nq, Nk):
+    """pm_attention_generic: the ViT-H/14 tower's 16 x 80 heads over 257 tokens, and the edges of its domain."""
+    ops = hip_ops_factory(dtype)
+    C = heads * D
+    q, k, v = rnd(B, Nq, C, dtype=dtype, seed=1), rnd(B, Nk, C, dtype=dtype, scale=1.3, seed=2), rnd(B, Nk, C, dtype=dtype, seed=3)
+    k[0, Nk - 1, :D] = 3 * q[0, 2, :D]  # a peaked row
+    want = REF.attention_generic(q, k, v, heads)
+    got = ops.attention_generic(q.cuda(), k.cuda(), v.cuda(), heads)
+    assert rel_err(got, want) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_prescaled_q(hip_ops_factory, dtype):
     """scale = ln 2 (scale * log2 e == 1): q is taken as already multiplied by 64^-1/2 log2 e, the kernel
     applies no scaling of its own (the U-Net folds the factor into the to_q weights)."""
