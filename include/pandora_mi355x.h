@@ -168,6 +168,24 @@ int pm_layernorm(const void* x, int64_t ldx, const float* gamma, const float* be
                  void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * pm_ln_gemm:  C[M, N] = epilogue( LayerNorm(X)[M, K] · W[N, K]^T )  in ONE kernel: the LayerNorm output never
+ * exists in HBM.  replaces the pairs norm1 -> attn1.to_q|k|v, norm2 -> attn2.to_q (or to_q|k|v), norm3 ->
+ * ff.net[0] (GEGLU) of BasicTransformerBlock._forward (attention.py:242-246 with :86-99 and :418-442) at the
+ * shallowest U-Net level, i.e. a pm_layernorm + pm_gemm call pair with identical results (same LayerNorm
+ * arithmetic, the normalised rows rounded to `dtype` once, f32 accumulation).
+ *   X f32 [M, K] (the residual stream; ldx % 4 == 0), gamma / beta f32 [K], W `dtype` [N, K] (ldw % 8 == 0),
+ *   C `dtype` [M, N] (ldc % 8 == 0) or, with PM_ACT_GEGLU, [M, N/2] (ldc % 4 == 0; W / bias packed as for pm_gemm).
+ *   epilogue: + bias[n] (may be NULL), or * bias[n] with PM_FLAG_BIAS_IS_SCALE (the only flag accepted); act is
+ *   PM_ACT_NONE or PM_ACT_GEGLU.  K must be 320 (a panel of 128 normalised rows stays in LDS for the sweep
+ *   over N; the level-1 width 640 was measured slower than the pair and is not served), N % 32 == 0.  pm_ln_gemm_supported says whether a shape is served AND worth it (enough
+ *   rows to amortise a workgroup's pass over W); callers use the pm_layernorm + pm_gemm pair otherwise.
+ */
+int pm_ln_gemm(const float* X, int64_t ldx, const float* gamma, const float* beta, float eps, const void* W,
+               int64_t ldw, const float* bias, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act,
+               int flags, int dtype, void* stream);
+int pm_ln_gemm_supported(int64_t M, int64_t N, int64_t K, int act);
+
+/* ------------------------------------------------------------------------------------------------
  * pm_attention: softmax(q k^T * scale) v with head dim 64, flash-style (no score matrix in HBM),
  * up to two key/value segments that share q and are softmax-normalised independently:
  *     out = attn(q, k1, v1) + w2 * attn(q, k2, v2)

@@ -37,6 +37,8 @@ class HipOps:
         self.fp8_min_tokens = int(fp8_min_tokens)  # shorter sequences stay on pm_attention (the packing pass costs more than it saves)
         if os.environ.get("PANDORA_Q_PRESCALE", "1") == "0":  # (numerics experiments: scale inside the kernel)
             self.q_prescale = None
+        # LayerNorm + projection pairs of the shallow levels as ONE kernel (pm_ln_gemm); "0": the two-kernel pair (A/B)
+        self.fused_ln = os.environ.get("PANDORA_FUSED_LN", "1") != "0"
         self.dtype = dtype
         self.dt = _DT[dtype]
         self.device = torch.device(device)
@@ -262,6 +264,26 @@ class HipOps:
         return out
 
     # -- attention -------------------------------------------------------------------------------
+    def ln_gemm(self, x, gamma, beta, w, bias=None, act="none", col_scale=None, eps=1e-5):
+        """gemm(layernorm(x), w, ...) for the f32 stream x: ONE kernel (pm_ln_gemm) where the shape is served,
+        the pm_layernorm + pm_gemm pair otherwise - same results either way."""
+        M, K = x.shape
+        N = w.shape[0]
+        code = capi.ACT_CODES[act]
+        if (self.fused_ln and x.dtype == torch.float32 and code in (capi.PM_ACT_NONE, capi.PM_ACT_GEGLU)
+                and self.lib.pm_ln_gemm_supported(M, N, K, code)):
+            assert w.shape[1] == K and w.is_contiguous() and w.dtype == self.dtype and x.stride(1) == 1
+            flags = 0
+            if col_scale is not None:
+                assert bias is None and col_scale.dtype == torch.float32 and col_scale.numel() == N
+                bias, flags = col_scale, capi.PM_FLAG_BIAS_IS_SCALE
+            out = self.empty(M, N // 2 if act == "geglu" else N)
+            rc = self.lib.pm_ln_gemm(_ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), eps, _ptr(w), K, _ptr(bias),
+                                     _ptr(out), out.stride(0), M, N, K, code, flags, self.dt, self._stream())
+            capi.check(rc, f"pm_ln_gemm M={M} N={N} K={K}")
+            return out
+        return self.gemm(self.layernorm(x, gamma, beta, eps), w, bias, act=act, col_scale=col_scale)
+
     def attention(self, q, k1, v1, heads, k2=None, v2=None, w2=1.0, out=None, prescaled=False):
         """q [B, Nq, heads*64] view; kX/vX [B or 1, NkX, heads*64] views (last dim contiguous).
         out = attn(q,k1,v1) + w2*attn(q,k2,v2), each softmax-normalised on its own.

@@ -446,11 +446,11 @@ class UNetModel(packing.PackedWeights, nn.Module):
         inner, heads = mod.inner, mod.heads
         v3 = lambda t, n: t.view(F, P, n)
         for which in (1, 2):
-            y = ops.layernorm(h, *e[f"ln{which}"])
+            ln = e[f"ln{which}"]  # (LayerNorm and the projection behind it are one op: ops.ln_gemm)
             key = f"a{which}_qkv"
             if key in e:  # self-attention, fused q|k|v projection
                 qs = e.get("a1_qscale") if which == 1 else None
-                qkv = v3(ops.gemm(y, e[key]) if qs is None else ops.gemm(y, e[key], col_scale=qs), 3 * inner)
+                qkv = v3(ops.ln_gemm(h, *ln, e[key], col_scale=qs), 3 * inner)
                 q, k, v = qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:]
                 if temporal:
                     if gather:  # frame-sharded without the pixel re-shard: all-gather K|V over frames
@@ -463,7 +463,7 @@ class UNetModel(packing.PackedWeights, nn.Module):
                 else:
                     a = ops.attention(q, k, v, heads)
             else:  # spatial cross-attention: text keys shared by all frames + per-frame image keys
-                q = v3(ops.gemm(y, e["a2_q"]), inner)
+                q = v3(ops.ln_gemm(h, *ln, e["a2_q"]), inner)
                 lo, hi = e["a2_kv_slice"]
                 kv_t = c.kv_text[:, lo:hi].unsqueeze(0)  # [1, 77, 2*inner] view of the batched projection
                 k2 = v2 = None
@@ -474,8 +474,7 @@ class UNetModel(packing.PackedWeights, nn.Module):
                     k2, v2 = kv_i[..., :inner], kv_i[..., inner:]
                 a = ops.attention(q, kv_t[..., :inner], kv_t[..., inner:], heads, k2, v2, 1.0)
             h = ops.gemm(a.view(F * P, inner), *e[f"a{which}_out"], residual=h, stream=True)
-        y = ops.layernorm(h, *e["ln3"])
-        g = ops.gemm(y, e["ff1"][0], e["ff1"][1], act="geglu")
+        g = ops.ln_gemm(h, *e["ln3"], e["ff1"][0], e["ff1"][1], act="geglu")
         # the block's last add: its only consumer is proj_out's A operand (16-bit anyway), so the sum
         # (formed in f32 against the f32 stream) is stored as 16 bit
         return ops.gemm(g, e["ff2"][0], e["ff2"][1], residual=h)

@@ -156,6 +156,9 @@ class TorchOps:
     def layernorm(self, x, gamma, beta, eps=1e-5, out=None):
         return self._out(F_.layer_norm(_f(x), (x.shape[1],), _f(gamma), _f(beta), eps), out)
 
+    def ln_gemm(self, x, gamma, beta, w, bias=None, act="none", col_scale=None, eps=1e-5):
+        return self.gemm(self.layernorm(x, gamma, beta, eps), w, bias, act=act, col_scale=col_scale)
+
     # -- attention -------------------------------------------------------------------------------
     def _attn(self, q, k, v, heads):
         B, Nq, C = q.shape

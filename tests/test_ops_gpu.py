@@ -222,6 +222,39 @@ def test_layernorm(hip_ops_factory, dtype, M, C):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,K,N,mode,nsplit", [
+    (4200, 320, 960, "scale", 0), (4200, 320, 960, "plain", 3), (4133, 320, 320, "bias", 0),
+    (4200, 320, 2560, "geglu", 0), (4200, 320, 2560, "geglu", 5), (4099, 320, 2560, "geglu", 3),
+    (4100, 320, 640, "plain", 1), (12288, 320, 960, "scale", 2), (40960, 320, 960, "scale", 0)])
+def test_ln_gemm_fused(hip_ops_factory, monkeypatch, dtype, M, K, N, mode, nsplit):
+    """pm_ln_gemm (LayerNorm + projection in one panel kernel: norm1/2/3 -> to_q|k|v / to_q / GEGLU ff.net[0],
+    attention.py:242-246) against the oracle's LayerNorm -> Linear, and against the two-kernel HIP pair; ragged
+    last panels (M % 128 != 0), every column split the host may choose, all three epilogues."""
+    ops = hip_ops_factory(dtype)
+    assert ops.fused_ln and ops.lib.pm_ln_gemm_supported(M, N, K, 2 if mode == "geglu" else 0)
+    if nsplit:
+        monkeypatch.setenv("PANDORA_LNGEMM_NSPLIT", str(nsplit))
+    x = rnd(M, K, dtype=torch.float32, scale=1.5, seed=1) - 0.4 + 2.0 * rnd(M, 1, dtype=torch.float32, seed=5)
+    gamma = 1 + 0.2 * rnd(K, dtype=torch.float32, seed=2)
+    beta = 0.3 * rnd(K, dtype=torch.float32, seed=3)
+    w = rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=4)
+    bias = rnd(N, dtype=torch.float32, seed=6) if mode in ("bias", "geglu") else None
+    scale = torch.cat([torch.full((N // 3,), 0.18033688), torch.ones(N - N // 3)]) if mode == "scale" else None
+    act = "geglu" if mode == "geglu" else "none"
+    want = REF.ln_gemm(x, gamma, beta, w, bias, act=act, col_scale=scale)
+    dx, dg, db, dw, dbias, dscale = dev(x, gamma, beta, w, bias, scale)
+    got = ops.ln_gemm(dx, dg, db, dw, dbias, act=act, col_scale=dscale)
+    assert got.shape == want.shape and got.dtype == dtype
+    assert rel_err(got, want) <= TOL[dtype]
+    pair = ops.gemm(ops.layernorm(dx, dg, db), dw, dbias, act=act, col_scale=dscale)
+    # same operands, same accumulation order: only a rare 1-ulp difference of a LayerNorm output (sum order) remains
+    assert rel_err(got, pair) <= 0.25 * TOL[dtype]
+    assert not ops.lib.pm_ln_gemm_supported(300, N, K, 0) and not ops.lib.pm_ln_gemm_supported(M, N, 640, 0)
+    small = ops.ln_gemm(dx[:300], dg, db, dw, dbias, act=act, col_scale=dscale)  # unserved shape: the pair runs
+    assert rel_err(small, want[:300]) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,heads,N", [(2, 2, 200), (1, 5, 640), (3, 1, 40), (2, 5, 2560)])
 def test_attention_self_fused_qkv(hip_ops_factory, dtype, B, heads, N):
     """Self-attention reading q, k, v as column slices of one fused [B, N, 3C] projection."""
