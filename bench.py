@@ -34,7 +34,7 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16, MI355X_MICROARCH.md
 T = 16
 
 KERNELS = {
-    "gemm": "pm_gemm (dense nn.Linear / 1x1: gemm_kernel<A_DENSE> 2-stage, gemm_ring_kernel<A_DENSE>, split-K reduce)",
+    "gemm": "pm_gemm + pm_ln_gemm (dense nn.Linear / 1x1: gemm_kernel<A_DENSE> 2-stage, gemm_ring_kernel<A_DENSE>, split-K reduce; ln_gemm_kernel = LayerNorm + projection at K = 320)",
     "conv3x3": "pm_conv2d_3x3 (gemm_ring_kernel<A_CONV3X3_FAST>; gemm_kernel for f32-operand / strided / upsampling convs)",
     "conv_t3": "pm_conv_temporal_k3 (gemm_kernel / gemm_ring_kernel<A_CONVT3>)",
     "attention": "pm_attention (attn_self_kernel: spatial self-attention; attn_kernel: text+image cross-attention)",
@@ -71,6 +71,15 @@ class TimedOps:
 
     def gemm(self, a, w, *args, **kw):
         r = self._timed("gemm", 2.0 * a.shape[0] * w.shape[0] * w.shape[1], self._ops.gemm, a, w, *args, **kw)
+        return r[0] if self.enabled else r
+
+    def ln_gemm(self, x, gamma, beta, w, *args, **kw):
+        # LayerNorm + projection: ONE launch (pm_ln_gemm) at the 320-wide level, counted with its GEMM FLOPs (the
+        # normalisation rides in the same kernel); elsewhere the pm_layernorm + pm_gemm pair, whose GEMM is timed
+        if not self._ops.fused_ln or not self._ops.lib.pm_ln_gemm_supported(x.shape[0], w.shape[0], x.shape[1],
+                                                                             2 if kw.get("act") == "geglu" else 0):
+            return self.gemm(self._ops.layernorm(x, gamma, beta), w, *args, **kw)
+        r = self._timed("gemm", 2.0 * x.shape[0] * w.shape[0] * w.shape[1], self._ops.ln_gemm, x, gamma, beta, w, *args, **kw)
         return r[0] if self.enabled else r
 
     def conv3x3(self, x, wp, bias, F, H, W, **kw):

@@ -21,7 +21,9 @@
 //     drift apart, so one wave's epilogue runs beside its SIMD partner's MFMAs.
 // Operand traffic per FLOP: W only, 4 KiB per 128x32x64 wave-step = half of the 128x128 tile kernel's A + W.
 // Measured (tools/lngemm_bench.py, profiles/r02/lngemm_*.txt): 1.2-1.5x the pm_layernorm + pm_gemm pair at K = 320;
-// K = 640 panels (96 or 64 rows) were built and measured at 0.7-1.1x and are not served (pm_ln_gemm_supported).
+// K = 640 panels (96 or 64 rows) were built and measured at 0.7-1.1x and are not served (pm_ln_gemm_supported);
+// lower panels at K = 320 (80 / 64 rows, three workgroups per CU) lose to the 128-row panel by 5-25 %: the W
+// fragments' L2 traffic per FLOP, not occupancy, is what the sweep is sensitive to.
 #include <stdlib.h>
 #include "common.hpp"
 
