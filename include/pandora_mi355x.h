@@ -54,6 +54,10 @@ extern "C" {
                                  * store) instead of adding: the softmax scale on the q third of a fused q|k|v
                                  * projection (attention.py:103 `* self.scale`), at no extra rounding */
 
+#define PM_FLAG_W_WRAP 32 /* pm_gemm, 16-bit A: W has K/2 columns and is walked twice, C = A[:, :K/2] W^T + A[:, K/2:] W^T.
+                           * With A = [hi | lo] from pm_split16 this is the split-operand product of PM_FLAG_A_LO in ONE
+                           * pass through the DMA-staged 16-bit kernels (K/2 % 64 == 0) */
+
 /* activation fused into a GEMM / conv epilogue */
 #define PM_ACT_NONE 0
 #define PM_ACT_SILU 1
@@ -166,6 +170,17 @@ int pm_groupnorm_apply(const void* x, int64_t ldx, const float* totals, const fl
 int pm_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y,
                  int64_t ldy, int64_t M, int64_t C, float eps, int in_dtype, int out_dtype,
                  void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * pm_split16: the f32 residual stream as a 16-bit GEMM / conv operand.  y[:, :K] = round(x) and, with_lo != 0,
+ * y[:, K:2K] = round(x - round(x)): what PM_FLAG_A_F32 (/ PM_FLAG_A_LO) do while staging, as one HBM-bound pass,
+ * so that the consumer runs on the DMA-staged 16-bit kernels (the register-staged f32 loaders run at a third of
+ * their rate).  Call sites: the 1x1 skip_connection of a width-changing ResBlock (openaimodel3d.py:185-190:
+ * [hi | lo] + PM_FLAG_W_WRAP), Downsample.op / Upsample.conv on the stream (:68-70, :96-108).
+ *   x f32 [M, K] (ldx % 4 == 0), y `dtype` [M, K or 2K] (ldy % 8 == 0), K % 8 == 0.
+ */
+int pm_split16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t M, int64_t K, int with_lo, int dtype,
+               void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * pm_ln_gemm:  C[M, N] = epilogue( LayerNorm(X)[M, K] · W[N, K]^T )  in ONE kernel: the LayerNorm output never

@@ -33,6 +33,7 @@ struct GemmParams {
   int out32, res32;  // f32 output / f32 residual (independent)
   int a_lo;          // PM_FLAG_A_LO (f32 A only): stage a - round16(a), the part the plain pass rounds away
   int bias_mul;      // PM_FLAG_BIAS_IS_SCALE: `bias` multiplies the accumulator (per-column scale) instead of adding
+  int kwrap;         // PM_FLAG_W_WRAP (dense): W has kwrap = K/2 columns, K-tile kt reads W columns (64 kt) mod kwrap (0: off)
   int ntiles, mtiles;
   int splits, ktps;  // split-K: number of K slices and K-tiles per slice
   float* ws;         // split-K partial slabs [splits][M][N] f32
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   auto load_tile = [&](int kt, int buf) {
     const int kb = kt * BK;
     const bool kin_l = kb + lc * 8 < p.K;  // only the general conv mode can have a K tail
-    const char* wb = Wb + (int64_t)kb * 2;
+    const char* wb = Wb + (int64_t)((AMODE == A_DENSE && p.kwrap && kb >= p.kwrap) ? kb - p.kwrap : kb) * 2;
     const char* ab = Ab;
     const char *hlo = nullptr, *hhi = nullptr;  // temporal mode: halo frames at this K-tile's channel (uniform)
     int dy = 0, dx = 0;
@@ -970,7 +971,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
       return true;
     };
     auto load_tile = [&](int kt, int buf) {
-      const char* wb = Wb + (int64_t)kt * (BK * 2);
+      const char* wb = Wb + (int64_t)((AMODE == A_DENSE && p.kwrap && kt * BK >= p.kwrap) ? kt * BK - p.kwrap : kt * BK) * 2;
       const char* ab = Ab;
       const char *hlo = nullptr, *hhi = nullptr;
       int dy = 0, dx = 0;
@@ -1519,7 +1520,9 @@ extern "C" int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, c
                        size_t workspace_bytes, float* colstats, void* stream) {
   int rc = check_common(A, W, C, M, N, K, act);
   if (rc) return rc;
-  if ((lda & ((flags & PM_FLAG_A_F32) ? 3 : 7)) || (ldw & 7) || lda < K || ldw < K) return PM_E_SHAPE;
+  const int64_t Kw = (flags & PM_FLAG_W_WRAP) ? K / 2 : K;  // columns of W
+  if ((flags & PM_FLAG_W_WRAP) && ((K % (2 * BK)) || (flags & PM_FLAG_A_F32))) return PM_E_SHAPE;
+  if ((lda & ((flags & PM_FLAG_A_F32) ? 3 : 7)) || (ldw & 7) || lda < K || ldw < Kw) return PM_E_SHAPE;
   if (!fits_u32(M * lda, flags) || N * ldw * 2 >= (1ll << 32)) return PM_E_SHAPE;  // 32-bit lane offsets
   if ((flags & PM_FLAG_OUT_F32) && act == PM_ACT_GEGLU) return PM_E_SHAPE;
   if ((flags & PM_FLAG_BIAS_IS_SCALE) && (bias == nullptr || act == PM_ACT_GEGLU)) return PM_E_SHAPE;
@@ -1531,6 +1534,7 @@ extern "C" int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, c
   p.res32 = (flags & (PM_FLAG_OUT_F32 | PM_FLAG_RES_F32)) ? 1 : 0;
   p.bias_mul = (flags & PM_FLAG_BIAS_IS_SCALE) ? 1 : 0;
   p.a_lo = (flags & PM_FLAG_A_LO) ? 1 : 0;
+  p.kwrap = (flags & PM_FLAG_W_WRAP) ? (int)Kw : 0;
   p.colstats = colstats;
   p.ntiles = (int)((N + BN - 1) / BN);
   p.zero = A;  // dense K tails never occur (K % 8 == 0 and whole chunks only); see kin below

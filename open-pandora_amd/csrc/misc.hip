@@ -172,6 +172,50 @@ extern "C" int pm_latent_affine(const float* x, const float* W, const float* b, 
                     return check_launch());
 }
 
+// f32 rows -> 16-bit rows: y[:, :K] = round16(x) and, with_lo, y[:, K:2K] = round16(x - round16(x)) (the part the
+// first rounding drops).  One thread per 8 elements: 2 x 16-byte loads, 1-2 x 16-byte stores.
+template <typename T>
+__global__ __launch_bounds__(256) void split16_kernel(const float* __restrict__ x, int64_t ldx, T* __restrict__ y,
+                                                      int64_t ldy, int64_t M, int K8, int with_lo) {
+  const int64_t total = M * K8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / K8;
+    const int c = (int)(i - m * K8) * 8;
+    const float* xp = x + m * ldx + c;
+    const pm::f32x4 a = *reinterpret_cast<const pm::f32x4*>(xp);
+    const pm::f32x4 b = *reinterpret_cast<const pm::f32x4*>(xp + 4);
+    pm::Pack8<T> hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hi.e[e] = pm::from_f32<T>(a[e]);
+      hi.e[e + 4] = pm::from_f32<T>(b[e]);
+    }
+    T* yp = y + m * ldy + c;
+    pm::st_global16(yp, hi.u);
+    if (with_lo) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        lo.e[e] = pm::from_f32<T>(a[e] - pm::to_f32(hi.e[e]));
+        lo.e[e + 4] = pm::from_f32<T>(b[e] - pm::to_f32(hi.e[e + 4]));
+      }
+      pm::st_global16(yp + (int64_t)K8 * 8, lo.u);
+    }
+  }
+}
+
+extern "C" int pm_split16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t M, int64_t K, int with_lo,
+                          int dtype, void* stream) {
+  if (!x || !y) return PM_E_NULL;
+  if (M < 1 || K < 8 || (K & 7) || (ldx & 3) || ldx < K || (ldy & 7) || ldy < (with_lo ? 2 * K : K)) return PM_E_SHAPE;
+  const int64_t total = M * (K / 8);
+  int64_t nb = (total + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  PM_DISPATCH_DTYPE(dtype, T,
+                    hipLaunchKernelGGL((split16_kernel<T>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x,
+                                       ldx, reinterpret_cast<T*>(y), ldy, M, (int)(K / 8), with_lo));
+  return pm::check_launch();
+}
+
 extern "C" const char* pm_strerror(int code) {
   switch (code) {
     case PM_OK: return "ok";

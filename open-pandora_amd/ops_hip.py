@@ -39,6 +39,9 @@ class HipOps:
             self.q_prescale = None
         # LayerNorm + projection pairs of the shallow levels as ONE kernel (pm_ln_gemm); "0": the two-kernel pair (A/B)
         self.fused_ln = os.environ.get("PANDORA_FUSED_LN", "1") != "0"
+        # f32 operands (the residual stream into skip 1x1 convs, Downsample / Upsample convs) are rounded by one
+        # pm_split16 pass and run on the DMA-staged 16-bit kernels; "0": the register-staged f32 loaders (A/B)
+        self.presplit = os.environ.get("PANDORA_PRESPLIT", "1") != "0"
         self.dtype = dtype
         self.dt = _DT[dtype]
         self.device = torch.device(device)
@@ -135,24 +138,41 @@ class HipOps:
         """out[M, N] = epi(a[M, K] @ w[N, K]^T); GEGLU halves N (weights pre-interleaved).
         col_scale f32 [N] (instead of a bias): column n is multiplied by col_scale[n] in f32 before the store.
         split_a (f32 `a`, stream output): two passes, a = hi + lo in 16 bit each (PM_FLAG_A_LO)."""
-        if split_a and a.dtype == torch.float32 and stream and act == "none":
+        wrap = 0
+        if a.dtype == torch.float32 and self.presplit and a.shape[1] % 64 == 0:
+            # the f32 stream as an operand of the DMA-staged 16-bit kernels: one pass of pm_split16 in front
+            # (split_a: [hi | lo] against W walked twice - the two-pass PM_FLAG_A_LO product in one launch)
+            both = split_a and stream and act == "none"
+            a = self.split16(a, with_lo=both)
+            wrap = capi.PM_FLAG_W_WRAP if both else 0
+        elif split_a and a.dtype == torch.float32 and stream and act == "none":
             y = self.gemm(a, w, bias, residual, out=out, stream=True)
             return self._gemm_lo(a, w, y, stats)
         M, K = a.shape
         N = w.shape[0]
-        assert w.shape[1] == K and w.is_contiguous() and w.dtype == self.dtype
+        assert w.shape[1] * (2 if wrap else 1) == K and w.is_contiguous() and w.dtype == self.dtype
         n_out = N // 2 if act == "geglu" else N
         flags, out = self._gemm_io(a, residual, out, M, n_out, stream)
+        flags |= wrap
         if col_scale is not None:
             assert bias is None and col_scale.dtype == torch.float32 and col_scale.numel() == N
             bias, flags = col_scale, flags | capi.PM_FLAG_BIAS_IS_SCALE
         col = self._stats_begin(M, n_out, stats, K)
-        rc = self.lib.pm_gemm(_ptr(a), self._rows(a, True), _ptr(w), K, _ptr(bias),
+        rc = self.lib.pm_gemm(_ptr(a), self._rows(a, True), _ptr(w), w.shape[1], _ptr(bias),
                               _ptr(residual), residual.stride(0) if residual is not None else 0,
                               _ptr(out), out.stride(0), M, N, K, capi.ACT_CODES[act], flags, self.dt,
                               _ptr(self.workspace), self.ws_bytes, _ptr(col[0] if col else None), self._stream())
         capi.check(rc, f"pm_gemm M={M} N={N} K={K}")
         return self._stats_end(out, col, stats)
+
+    def split16(self, x, with_lo=False):
+        """f32 [M, K] -> 16-bit [M, K] (rounded) or [M, 2K] = [hi | lo] with lo = round(x - hi)  (pm_split16)."""
+        M, K = x.shape
+        assert x.dtype == torch.float32 and x.stride(1) == 1
+        y = self.empty(M, 2 * K if with_lo else K)
+        rc = self.lib.pm_split16(_ptr(x), x.stride(0), _ptr(y), y.stride(0), M, K, int(with_lo), self.dt, self._stream())
+        capi.check(rc, f"pm_split16 M={M} K={K}")
+        return y
 
     def _gemm_lo(self, a, w, y, stats):
         """y += (a - round16(a)) @ w^T, in place (y f32); fused statistics, if wanted, come from this final pass."""
@@ -169,6 +189,8 @@ class HipOps:
     def conv3x3(self, x, wp, bias, F, H, W, stride=1, upsample=False, residual=None, out=None, stream=False,
                 pad_lo=1, stats=None):
         """x [F*H*W, Cin] -> [F*Ho*Wo, Cout]; wp packed [Cout, 9*Cin]."""
+        if x.dtype == torch.float32 and self.presplit:
+            x = self.split16(x)  # the f32 stream (Downsample / Upsample): rounded once here, then the DMA loaders
         cin = x.shape[1]
         cout = wp.shape[0]
         assert x.shape[0] == F * H * W and wp.shape[1] == 9 * cin and wp.is_contiguous()
@@ -187,6 +209,8 @@ class HipOps:
     def conv_t3(self, x, wp, bias, F, P, residual=None, halo_lo=None, halo_hi=None, out=None, stream=False,
                 stats=None):
         """3-tap conv over frames: x [F*P, Cin] -> [F*P, Cout]; wp packed [Cout, 3*Cin]."""
+        if x.dtype == torch.float32 and self.presplit and halo_lo is None and halo_hi is None:
+            x = self.split16(x)
         cin = x.shape[1]
         cout = wp.shape[0]
         assert x.shape[0] == F * P and wp.shape[1] == 3 * cin and wp.is_contiguous()

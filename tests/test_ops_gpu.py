@@ -77,6 +77,35 @@ def test_gemm_split_f32_operand(hip_ops_factory, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(300, 320, 640), (2560, 1280, 2560), (4099, 320, 960)])
+def test_split16_and_wrapped_weights(hip_ops_factory, monkeypatch, dtype, M, N, K):
+    """pm_split16 is bit-exact ([hi | lo] = the roundings PM_FLAG_A_F32 / PM_FLAG_A_LO apply while staging), and
+    the one-pass [hi | lo] x W-walked-twice product (PM_FLAG_W_WRAP) equals the two-pass register-staged one."""
+    ops = hip_ops_factory(dtype)
+    a = rnd(M, K, dtype=torch.float32, scale=2.0, seed=1)
+    hl = ops.split16(a.cuda(), with_lo=True).cpu()
+    hi = a.to(dtype)
+    assert torch.equal(hl[:, :K], hi) and torch.equal(hl[:, K:], (a - hi.float()).to(dtype))
+    assert torch.equal(ops.split16(a.cuda()).cpu(), hi)
+    w, bias = rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=2), rnd(N, dtype=torch.float32, seed=3)
+    res = rnd(M, N, dtype=torch.float32, seed=4)
+    want = a @ w.float().t() + bias + res
+    assert ops.presplit
+    one, tot = ops.gemm(a.cuda(), w.cuda(), bias.cuda(), residual=res.cuda(), stream=True, split_a=True, stats=(1, 32))
+    monkeypatch.setattr(ops, "presplit", False)
+    two = ops.gemm(a.cuda(), w.cuda(), bias.cuda(), residual=res.cuda(), stream=True, split_a=True)
+    tol = 2e-5 if dtype == torch.float16 else 1e-4
+    assert rel_err(one, want) <= tol and rel_err(two, want) <= tol and rel_err(one, two) <= 1e-6
+    assert rel_err(tot, TorchOps._with_stats(want, (1, 32))[1]) <= 1e-4
+    # plain f32 operand (rounded once): the pre-rounded DMA path equals the register-staged one bit for bit
+    monkeypatch.setattr(ops, "presplit", True)
+    p1 = ops.gemm(a.cuda(), w.cuda(), bias.cuda(), stream=True)
+    monkeypatch.setattr(ops, "presplit", False)
+    p0 = ops.gemm(a.cuda(), w.cuda(), bias.cuda(), stream=True)
+    assert rel_err(p1, p0) <= 1e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_exact_integers(hip_ops_factory, dtype):
     """Small-integer operands make every product and sum exact: any fragment-layout mistake
     (row/col swap, k permutation) shows up as a mismatch, not as rounding."""

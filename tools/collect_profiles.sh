@@ -26,6 +26,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write --
 python3 tools/pmc_table.py $O/pmc_write > $O/pmc_write.txt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_calib -- python3 tools/fetch_calib.py > $O/fetch_calib.txt 2>/dev/null
 python3 tools/pmc_table.py $O/pmc_calib >> $O/fetch_calib.txt
+python3 tools/lngemm_bench.py --reps 30 > $O/lngemm_ab.txt 2>/dev/null
 # 4. attention A/B (bf16 variants + fp8) and its SQ counters
 python3 tools/attn_bench.py --rounds 7 --variants 9,1,3,5,101 > $O/attention_ab.txt 2>/dev/null
 rocprofv3 --kernel-trace --pmc $PMC_SQ --output-format csv -d $O/pmc_attn -- python3 tools/attn_pmc.py > /dev/null 2>&1

@@ -1,7 +1,7 @@
 """A few launches of the dominant kernels at the U-Net's shapes, for rocprofv3 --pmc passes (HBM-side traffic:
 FETCH_SIZE and WRITE_SIZE in separate runs; SQ counters in a third).  Shapes: the dense GEMM family's heaviest
 (GEGLU ff1 at level 0 / level 1, the q|k|v projection, the f32-stream out-projection with residual), the level-0
-3x3 conv, and the spatial self-attention at N = 2560 (320x512) and N = 9216 (576x1024)."""
+3x3 conv, the LayerNorm + projection panel kernel (pm_ln_gemm), and the spatial self-attention at N = 2560 (320x512) and N = 9216 (576x1024)."""
 import os
 import sys
 
@@ -34,6 +34,16 @@ w_o = r(C, C) * 0.05
 res = torch.randn(M, C, device="cuda")
 for _ in range(REP):
     ops.gemm(x, w_o, z(C), residual=res, stream=True)              # M=40960 N=320 K=320, f32 residual + output
+xf = torch.randn(M, C, device="cuda") * 1.5
+g1, b1 = torch.ones(C, device="cuda"), z(C)
+for _ in range(REP):
+    ops.ln_gemm(xf, g1, b1, w_qkv)                                 # pm_ln_gemm: LayerNorm + q|k|v, M=40960 N=960 K=320
+for _ in range(REP):
+    ops.ln_gemm(xf, g1, b1, w_ff1, z(8 * C), act="geglu")          # pm_ln_gemm: LayerNorm + GEGLU ff1, N=2560
+xf2 = torch.randn(16 * 72 * 128, C, device="cuda") * 1.5
+for _ in range(REP):
+    ops.ln_gemm(xf2, g1, b1, w_ff1, z(8 * C), act="geglu")         # the same at 576x1024: M=147456
+del xf2
 for N in (2560, 9216):
     qkv = r(16, N, 960)
     for _ in range(REP):

@@ -47,6 +47,11 @@ class Prof:
             tag = f"{name} M={M} N={w.shape[0]} K={K} a={str(x.dtype)[6:]} o={str(out.dtype)[6:]}" \
                   f"{' act=' + kw['act'] if kw.get('act') else ''}{' res' if res is not None else ''}{' stats' if kw.get('stats') else ''}"
             return tag, 2.0 * M * w.shape[0] * K, byts
+        if name == "ln_gemm":  # LayerNorm + projection (one kernel at K = 320, else the pm_layernorm + pm_gemm pair)
+            x, w = a[0], a[3]
+            byts = esz(x) + esz(w) + esz(out)
+            return f"ln_gemm M={x.shape[0]} N={w.shape[0]} K={w.shape[1]} a={str(x.dtype)[6:]} o={str(out.dtype)[6:]}" \
+                   f"{' act=' + kw['act'] if kw.get('act') else ''}", 2.0 * x.shape[0] * w.shape[0] * w.shape[1], byts
         tens = [t for t in list(a) + list(kw.values()) if isinstance(t, torch.Tensor)]
         big = max(tens, key=lambda t: t.numel()) if tens else None
         byts = sum(esz(t) for t in tens) + (esz(out) if isinstance(out, torch.Tensor) else 0)
