@@ -1349,6 +1349,7 @@ static int g_ring_max_work = 0;  // PANDORA_GEMM_RING_MAX_WORK > 0: never use th
 static int g_num_cus[MAX_DEVICES] = {0};
 static int g_persist_per_cu = 0;    // PANDORA_GEMM_PERSIST: persistent 2-stage workgroups per CU (0 = one work item per workgroup; measured: 2/CU = no gain, 1 or 3/CU 5 % slower)
 static int g_split_min_nk = 24;     // PANDORA_SPLITK_MIN_NK: shortest K loop (in 64-wide tiles) that is split
+static int g_split_model = 1;       // PANDORA_SPLITK_MODEL: 0 = the round-1 rule (aim at 512 work items), for A/B runs
 
 static int current_device() {
   int dev = 0;
@@ -1367,6 +1368,8 @@ static void init_once() {
     if (r) g_ring = atoi(r);
     const char* rw = getenv("PANDORA_GEMM_RING_MAX_WORK");
     if (rw) g_ring_max_work = atoi(rw);
+    const char* sm = getenv("PANDORA_SPLITK_MODEL");
+    if (sm) g_split_model = atoi(sm);
     const char* ps = getenv("PANDORA_GEMM_PERSIST");
     if (ps) g_persist_per_cu = atoi(ps);
     return true;
@@ -1374,24 +1377,54 @@ static void init_once() {
   (void)init;
 }
 
-static int choose_splits(int64_t M, int64_t N, int64_t K, int act, int* ktps) {
+// Split-K plan of a call shape.  Few-tile grids (the deep U-Net levels) can cut their K loop over several
+// workgroups, but the slabs cost a second pass: s partial [M, N] f32 slabs written by the main kernel, read by
+// the reduce launch.  The old rule (aim at 512 work items) split 200-tile grids three ways - 600 items run in
+// three rounds of one workgroup per CU, no shorter than the unsplit round, plus the reduce: the temporal convs at
+// M = 2560 ran 64 us against 42 unsplit - and cut 50-tile grids 11 ways where 5 fill the chip once.  Now: the s
+// that minimises  rounds(s) x (K-steps per slice x t_step + t_fixed) + reduce(s)  with the ring kernel's measured
+// step (0.55 us per 64-wide K-step per workgroup, ~2 us of prologue + epilogue per round) and the slabs' HBM time.
+static int choose_splits(int64_t M, int64_t N, int64_t K, int act, int* ktps, bool two_stage = false) {
   init_once();
   const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   const int nk = (int)((K + BK - 1) / BK);
   *ktps = nk;
   if (act == PM_ACT_GEGLU || tiles >= 384 || nk < g_split_min_nk) return 1;
-  int64_t s = (512 + tiles - 1) / tiles;
-  if (s > nk / 4) s = nk / 4;
-  if (s > 32) s = 32;
-  if (s < 2) return 1;
-  *ktps = (int)((nk + s - 1) / s);
-  return (nk + *ktps - 1) / *ktps;
+  // the general 3x3 mode (nearest-x2 upsample) only runs on the 2-stage kernel, two workgroups per CU, where a
+  // single round of <= 256 tiles is round-trip-bound: it keeps the 512-item rule; so do very long K loops, where
+  // three slices of a 360-step loop measured 11 % faster than the unsplit run (narrower K window per XCD L2)
+  if (g_split_model == 0 || two_stage || nk >= 256) {
+    int64_t s = (512 + tiles - 1) / tiles;
+    if (s > nk / 4) s = nk / 4;
+    if (s > 32) s = 32;
+    if (s < 2) return 1;
+    *ktps = (int)((nk + s - 1) / s);
+    return (nk + *ktps - 1) / *ktps;
+  }
+  const double cus = 256.0, t_step = 0.55, t_fixed = 2.0;  // (a fixed CU count: the plan must not depend on the device)
+  const double slab_us = (double)M * (double)N * 8.0 / 4.5e6;  // one slab written + read, at ~4.5 TB/s
+  int best_s = 1, best_ktps = nk;
+  double best = 0.0;
+  for (int s = 1; s <= 32 && s <= nk / 4; ++s) {
+    const int kt = (nk + s - 1) / s, splits = (nk + kt - 1) / kt;
+    if (s > 1 && splits != s) continue;  // (the same plan as a smaller s)
+    const double rounds = (double)((tiles * splits + (int64_t)cus - 1) / (int64_t)cus);
+    const double cost = rounds * (kt * t_step + t_fixed) + (splits > 1 ? 2.5 + splits * slab_us : 0.0);
+    if (s == 1 || cost < best * 0.97) {
+      best = cost;
+      best_s = splits;
+      best_ktps = kt;
+    }
+  }
+  *ktps = best_ktps;
+  return best_s;
 }
 
-static void plan_split(GemmParams& p, void* workspace, size_t workspace_bytes) {
+static void plan_split(GemmParams& p, void* workspace, size_t workspace_bytes, bool two_stage = false) {
   init_once();
   int ktps;
-  int s = choose_splits(p.M, p.N, p.K, p.act, &ktps);
+  // (a call with fused statistics keeps the plan pm_gemm_colstats_rows answers for: its colstats are sized by it)
+  int s = choose_splits(p.M, p.N, p.K, p.act, &ktps, two_stage && p.colstats == nullptr);
   // fused statistics: from the main kernel's epilogue when the call runs unsplit (64-row blocks), from the
   // reduce pass when it splits (16-row blocks, pm_gemm_colstats_rows); the reduce variant needs 4-column vectors
   if (p.colstats != nullptr && s > 1 && ((p.N & 3) || p.act == PM_ACT_GEGLU)) {  // (pm_gemm_colstats_rows says 64 too)
@@ -1578,7 +1611,7 @@ extern "C" int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const f
     p.tap_a[t] = ((int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * ldx * 2;
     p.tap_w[t] = (int64_t)t * Cin * 2;
   }
-  plan_split(p, workspace, workspace_bytes);
+  plan_split(p, workspace, workspace_bytes, /*two_stage=*/upsample2x || (Cin % BK) != 0);
   if (p.colstats != nullptr && p.splits > 1 && ((p.ldc & 3) || (p.R != nullptr && (p.ldr & 3)))) return PM_E_SHAPE;
   if (!upsample2x && (Cin % BK) == 0)
     PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_CONV3X3_FAST>(p, flags, (hipStream_t)stream)));

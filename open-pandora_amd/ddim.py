@@ -83,6 +83,71 @@ class _ForwardGraph:
         return self.e_c, self.e_u
 
 
+class _SegmentedForward:
+    """A frame-sharded U-Net forward (frame_parallel.FrameParallel) has ~140 exchanges inside, which a HIP graph of
+    the whole forward cannot hold; issued eagerly, its ~1100 launches cost ~10 ms of host time per forward - more
+    than the sharded kernels take at 4 or 8 ranks.  Here the kernels BETWEEN two exchanges are captured as HIP
+    graphs that share one memory pool, and a step replays [graph 0, exchange 0, graph 1, ..., graph n] in order:
+    the exchanges stay ordinary RCCL calls on the replay stream, re-issued on the buffers they were recorded
+    with (FrameParallel allocates them before the call, inside the preceding segment, from the graphs' pool).
+    Recording executes each segment right after capturing it (graph replay), so every exchange sees real data and
+    all ranks walk the same sequence of collectives as an eager forward."""
+
+    def __init__(self, model, x, t, c, fs, kwargs, fp):
+        self.x, self.t = x.clone(), t.clone()
+        dev = x.device
+        self._side = torch.cuda.Stream(device=dev)
+        self._side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self._side):  # warm-up on the capture stream: weights packed, split-K scratch sized
+            model.apply_model(self.x, self.t, c, fs=fs, **kwargs)
+        torch.cuda.current_stream(dev).wait_stream(self._side)
+        torch.cuda.synchronize(dev)
+        self.steps = []
+        self._pool = torch.cuda.graph_pool_handle()
+        self._ctx = None
+        fp.recorder = self
+        try:
+            self._begin()
+            self.out = model.apply_model(self.x, self.t, c, fs=fs, **kwargs)
+            self._end()
+        except BaseException:
+            if self._ctx is not None:  # leave capture mode before the caller falls back to an eager forward
+                try:
+                    self._ctx.__exit__(None, None, None)
+                except Exception:
+                    pass
+            raise
+        finally:
+            fp.recorder = None
+
+    def _begin(self):
+        self._g = torch.cuda.CUDAGraph()
+        self._ctx = torch.cuda.graph(self._g, pool=self._pool, stream=self._side)
+        self._ctx.__enter__()
+
+    def _end(self):
+        self._ctx.__exit__(None, None, None)
+        self._ctx = None
+        self.steps.append(self._g)
+
+    def comm(self, fn):
+        self._end()
+        self._g.replay()  # run the segment just captured: the exchange needs its real outputs
+        fn()
+        self.steps.append(fn)
+        self._begin()
+
+    def __call__(self, x, t):
+        self.x.copy_(x)
+        self.t.copy_(t)
+        for s in self.steps:
+            if isinstance(s, torch.cuda.CUDAGraph):
+                s.replay()
+            else:
+                s()
+        return self.out
+
+
 class DDIMSampler:
     def __init__(self, model, schedule="linear", use_graph=None, cfg_parallel=None, ops=None, **kwargs):
         """`ops`: the op table for the fused update kernel; default = the one bound to model's U-Net.  Pass it
@@ -97,6 +162,7 @@ class DDIMSampler:
         # HIP-graph replay of the forwards (single-GPU HipOps only; PANDORA_HIPGRAPH=0 disables)
         self.use_graph = (os.environ.get("PANDORA_HIPGRAPH", "1") != "0") if use_graph is None else use_graph
         self._graphs = {}
+        self._seg_failed = False  # a segmented capture raised once: eager from then on
         self._gen = None  # multi-rank noise generator (see _draw)
 
     def _fp(self):
@@ -223,14 +289,46 @@ class DDIMSampler:
                 g = self._graphs[key] = _ForwardGraph(self.model, x, t, cc, uu, fs, kwargs)
             return g(x, t)
 
+        fp_u = getattr(unet, "fp", None)
+        # frame shards: HIP graphs of the segments between the in-forward exchanges (RCCL only; PANDORA_SEGMENT_GRAPHS=0
+        # or a failed capture: the eager forward)
+        segmentable = (self.use_graph and getattr(ops, "supports_graphs", False) and isinstance(c, dict) and x.is_cuda
+                       and fp_u is not None and fp_u.backend == "nccl" and not self._seg_failed
+                       and os.environ.get("PANDORA_SEGMENT_GRAPHS", "1") != "0")
+
+        def forward_sharded(cc, slot):
+            if segmentable:
+                tensors = [v for lst in cc.values() for v in lst] + ([fs] if torch.is_tensor(fs) else [])
+                key = ("seg", slot, tuple(x.shape), tuple((v.data_ptr(), tuple(v.shape)) for v in tensors),
+                       tuple(sorted(kwargs)), getattr(unet, "_pack_epoch", 0))
+                g = self._graphs.get(key)
+                if g is None:
+                    for k in [k for k in self._graphs if k[0] == "seg" and k[1] == slot]:
+                        del self._graphs[k]
+                    try:
+                        g = self._graphs[key] = _SegmentedForward(self.model, x, t, cc, fs, kwargs, fp_u)
+                    except Exception as exc:  # e.g. an RCCL build that refuses calls next to a capture
+                        import warnings
+                        warnings.warn(f"segmented graph capture of the frame-sharded forward failed ({exc!r}): eager")
+                        self._seg_failed = True
+                        return self.model.apply_model(x, t, cc, fs=fs, **kwargs)
+                return g(x, t)
+            return self.model.apply_model(x, t, cc, fs=fs, **kwargs)
+
         if pair:
-            # the branch forward has no collective inside (frames unsharded): it replays as a graph too,
-            # the exchange of the two branch outputs stays outside the graph
+            # this rank runs ONE branch; the exchange of the two branch outputs stays outside any graph.  Without
+            # frame shards the branch forward has no collective inside and replays as one graph
             mine = c if self.cfg_parallel.branch == 0 else uc
-            e_mine = replay(mine, None)[0] if graphable else self.model.apply_model(x, t, mine, fs=fs, **kwargs)
+            if fp_u is not None:
+                e_mine = forward_sharded(mine, 0)
+            else:
+                e_mine = replay(mine, None)[0] if graphable else self.model.apply_model(x, t, mine, fs=fs, **kwargs)
             e_c, e_u = self.cfg_parallel.exchange(e_mine)
         elif graphable and self.cfg_parallel is None:
             e_c, e_u = replay(c, uc)
+        elif fp_u is not None:
+            e_c = forward_sharded(c, 0)
+            e_u = forward_sharded(uc, 1) if use_cfg else None
         else:
             e_c = self.model.apply_model(x, t, c, fs=fs, **kwargs)
             e_u = self.model.apply_model(x, t, uc, fs=fs, **kwargs) if use_cfg else None

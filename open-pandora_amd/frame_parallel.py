@@ -47,6 +47,21 @@ class FrameParallel:
         self.frame_offset = self.rank * self.local_frames
         self.backend = dist.get_backend(group)
         self.calls = {"reduce_stats": 0, "exchange_halo": 0, "all_to_all": 0, "stats_halo": 0}
+        # ddim._SegmentedForward while it records a forward: every in-forward exchange is handed to it as a
+        # closure over buffers that were allocated BEFORE the call (so a replay re-issues the same RCCL calls on
+        # the same addresses, between the HIP graphs that hold the kernels around them)
+        self.recorder = None
+
+    def _comm(self, fn):
+        if self.recorder is None:
+            fn()
+        else:
+            self.recorder.comm(fn)
+
+    @staticmethod
+    def _p2p(ops):
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
 
     # ---- clip-level helpers (sampler boundary) --------------------------------------------------
     def shard_frames(self, x, dim=2):
@@ -73,7 +88,7 @@ class FrameParallel:
         self.calls["reduce_stats"] += 1
         tot = partial.contiguous().clone()
         _host_staged_sync(tot, self.group)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
+        self._comm(lambda: dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group))
         return tot, float(local_count) * self.world
 
     def exchange_halo(self, t, P):
@@ -91,8 +106,8 @@ class FrameParallel:
         if self.rank < self.world - 1:
             ops += [dist.P2POp(dist.isend, last, self._global(self.rank + 1), self.group),
                     dist.P2POp(dist.irecv, hi, self._global(self.rank + 1), self.group)]
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+        if ops:
+            self._comm(lambda: self._p2p(ops))
         return lo, hi
 
     def exchange_stats_halo(self, x, P, partial, local_count):
@@ -122,8 +137,8 @@ class FrameParallel:
         if self.rank < self.world - 1:
             ops += [dist.P2POp(dist.isend, last, self._global(self.rank + 1), self.group),
                     dist.P2POp(dist.irecv, hi, self._global(self.rank + 1), self.group)]
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+        if ops:
+            self._comm(lambda: self._p2p(ops))
         tot = parts[0].clone()
         for r in range(1, self.world):
             tot += parts[r]
@@ -132,7 +147,7 @@ class FrameParallel:
     def _a2a(self, src):
         dst = torch.empty_like(src)
         _host_staged_sync(src, self.group)
-        dist.all_to_all_single(dst, src, group=self.group)
+        self._comm(lambda: dist.all_to_all_single(dst, src, group=self.group))
         return dst
 
     def frames_to_pixels(self, t, P):
@@ -163,9 +178,9 @@ class FrameParallel:
                              device=kv_local.device)
         if self.backend == "gloo":
             parts = list(kv_all.chunk(self.world, dim=0))
-            dist.all_gather(parts, kv_local, group=self.group)
+            self._comm(lambda: dist.all_gather(parts, kv_local, group=self.group))
         else:
-            dist.all_gather_into_tensor(kv_all, kv_local, group=self.group)
+            self._comm(lambda: dist.all_gather_into_tensor(kv_all, kv_local, group=self.group))
         return kv_all[..., :inner], kv_all[..., inner:]
 
 
