@@ -53,6 +53,7 @@ class TimedOps:
     def reset(self):
         self.ev = {k: [] for k in KERNELS}
         self.fl = {k: 0.0 for k in KERNELS}
+        self.by = {k: 0.0 for k in KERNELS}  # algorithmic HBM bytes: every operand and the output once
         self.attn_big = ([], 0.0)  # (events, flops) of the self-attention launches with Nq == Nk >= 9216
 
     def __getattr__(self, k):
@@ -67,6 +68,10 @@ class TimedOps:
         e1.record()
         self.ev[fam].append((e0, e1))
         self.fl[fam] += flops
+        esz = lambda t: t.numel() * t.element_size()
+        out = y[0] if isinstance(y, tuple) else y
+        self.by[fam] += (sum(esz(t) for t in list(a) + list(kw.values()) if torch.is_tensor(t) and t.numel() > 4096)
+                         + (esz(out) if torch.is_tensor(out) and kw.get("out") is None else 0.0))
         return y, (e0, e1)
 
     def gemm(self, a, w, *args, **kw):
@@ -120,7 +125,7 @@ class TimedOps:
         out = {}
         for fam in KERNELS:
             ms = sum(a.elapsed_time(b) for a, b in self.ev[fam])
-            out[fam] = {"ms": ms, "launches": len(self.ev[fam]), "flops": self.fl[fam]}
+            out[fam] = {"ms": ms, "launches": len(self.ev[fam]), "flops": self.fl[fam], "bytes": self.by[fam]}
         ev, fl = self.attn_big
         big = {"ms": sum(a.elapsed_time(b) for a, b in ev), "launches": len(ev), "flops": fl}
         return out, big
@@ -266,8 +271,11 @@ def main():
         fam_out = {}
         for k, v in fams.items():
             tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
+            tbs = v["bytes"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
             fam_out[k] = {"ms_per_step": v["ms"] / 2.0, "launches_per_step": v["launches"] // 2,
                           "tflops": tf, "frac_of_peak": tf / MFMA_PEAK_TFLOPS,
+                          # the same launches against the OTHER roofline: algorithmic bytes (operands + output once)
+                          "algorithmic_TBps": tbs, "frac_of_hbm_8TBps": tbs / 8.0,
                           "share_of_step_time": (v["ms"] * 1e-3 / 2.0) / step_s}
         return {"res": res, "latent": [T, h, w], "steps": steps, "elapsed": elapsed, "step_s": step_s,
                 "families": fam_out, "raw": fams, "attn_big": big, "x": x, "ins": ins}
@@ -343,6 +351,10 @@ def main():
             ach = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
             return {"bound": "mfma", "kernel": KERNELS[fam], "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                    "hbm_view": {"achieved": r["families"][fam]["algorithmic_TBps"], "peak": 8.0, "unit": "TB/s",
+                                 "frac": r["families"][fam]["frac_of_hbm_8TBps"],
+                                 "note": "algorithmic bytes of the same launches / the same time: the family mixes "
+                                         "MFMA-bound and HBM-bound shapes (DESIGN.md section 3)"},
                     "launches": v["launches"], "avg_launch_ms": v["ms"] / max(1, v["launches"]),
                     "share_of_step_time": r["families"][fam]["share_of_step_time"],
                     "chosen_by": "largest summed HIP-event time among the MFMA kernel families of this run",

@@ -151,6 +151,13 @@ class HipOps:
         M, K = a.shape
         N = w.shape[0]
         assert w.shape[1] * (2 if wrap else 1) == K and w.is_contiguous() and w.dtype == self.dtype
+        if K % 64 and not wrap:
+            # pm_gemm walks whole 64-wide K-tiles (every Linear of the U-Net has K % 64 == 0); narrower models (the
+            # reduced-width first-stage encoder's 1x1 shortcut) get both operands zero-padded along K: same product
+            pad = 64 - K % 64
+            a = torch.nn.functional.pad(a, (0, pad))
+            w = torch.nn.functional.pad(w, (0, pad))
+            K += pad
         n_out = N // 2 if act == "geglu" else N
         flags, out = self._gemm_io(a, residual, out, M, n_out, stream)
         flags |= wrap

@@ -373,10 +373,9 @@ class UNetModel(packing.PackedWeights, nn.Module):
     def _gn(self, c, x, gb, eps, silu, per_frame, totals=None):
         """`totals`: {sum, sumsq} already produced by the epilogue of the op that wrote x."""
         ops = c.ops
-        if totals is None:  # statistics a previous module's last op left behind for this very tensor
-            hit = c.stats.pop(x.data_ptr(), None)
-            if hit is not None and hit[1] == tuple(x.shape):
-                tot = hit[0]
+        if totals is None:  # statistics a previous module's last op left behind ON this very tensor object
+            tot = getattr(x, "_pm_gn_totals", None)
+            if tot is not None:
                 need = c.F if per_frame else 1
                 if tot.shape[0] == need:
                     totals = tot
@@ -395,9 +394,11 @@ class UNetModel(packing.PackedWeights, nn.Module):
 
     @staticmethod
     def _keep_stats(c, out_tot):
+        # the statistics ride on the tensor OBJECT the op returned (a Python attribute): a view, a copy or another
+        # tensor that later occupies the same address never carries them (they used to be keyed by data_ptr())
         out, tot = out_tot
         if tot is not None:
-            c.stats[out.data_ptr()] = (tot, tuple(out.shape))
+            out._pm_gn_totals = tot
         return out
 
     def _res_block(self, c, mod, x, out=None):
@@ -501,10 +502,6 @@ class UNetModel(packing.PackedWeights, nn.Module):
         layers = list(seq)
         for li, layer in enumerate(layers):
             dst = out if li == len(layers) - 1 else None
-            # the only statistics worth keeping are those of this layer's (live) input: an entry of a tensor
-            # that has been freed meanwhile could otherwise meet a new tensor at the same address
-            if c.stats:
-                c.stats = {k: v for k, v in c.stats.items() if k == h.data_ptr()}
             if isinstance(layer, ResBlock):
                 h = self._res_block(c, layer, h, dst)
             elif isinstance(layer, SpatialTransformer):
@@ -577,7 +574,6 @@ class UNetModel(packing.PackedWeights, nn.Module):
         assert b == 1, "the reference path runs batch size 1 (model.py:794)"
         c = _Ctx()
         c.ops, c.fp, c.w = self.ops, self.fp, packed
-        c.stats = {}  # data_ptr -> (GroupNorm totals, shape) left behind by the op that wrote that stream tensor
         c.F, c.H, c.W = t, hh, ww
         ops = c.ops
         T_total = t if c.fp is None else c.fp.total_frames

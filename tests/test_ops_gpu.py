@@ -372,12 +372,21 @@ def test_ddim_update_and_layout(hip_ops_factory, dtype):
 
 
 def test_bad_arguments_raise(hip_ops_factory):
-    from open_pandora_amd.capi import PandoraKernelError
+    from open_pandora_amd import capi
     ops = hip_ops_factory(torch.float16)
-    a = torch.zeros(16, 72, dtype=torch.float16).cuda()  # K = 72 is not a multiple of 64
-    w = torch.zeros(8, 72, dtype=torch.float16).cuda()
-    with pytest.raises(PandoraKernelError):
-        ops.gemm(a, w)
+    a = rnd(16, 72, dtype=torch.float16, seed=1).cuda()  # K = 72 is not a multiple of 64
+    w = rnd(8, 72, dtype=torch.float16, seed=2).cuda()
+    out = torch.empty(16, 8, dtype=torch.float16, device="cuda")
+    # the C-ABI refuses a K that is not whole 64-wide tiles ...
+    rc = ops.lib.pm_gemm(a.data_ptr(), 72, w.data_ptr(), 72, None, None, 0, out.data_ptr(), 8, 16, 8, 72, 0, 0,
+                         capi.PM_F16, None, 0, None, torch.cuda.current_stream().cuda_stream)
+    assert rc == -2
+    with pytest.raises(capi.PandoraKernelError):
+        capi.check(rc, "pm_gemm K=72")
+    with pytest.raises(capi.PandoraKernelError):  # (and HipOps surfaces any refusal as an exception)
+        ops.layernorm(torch.zeros(4, 12, dtype=torch.float16).cuda(), torch.ones(12).cuda(), torch.zeros(12).cuda())
+    # ... the op table serves it by zero-padding both operands along K (reduced-width first-stage encoder)
+    assert rel_err(ops.gemm(a, w), a.float().cpu() @ w.float().cpu().t()) <= TOL[torch.float16]
 
 
 # ---- f32 residual stream variants (PM_FLAG_A_F32 / PM_FLAG_OUT_F32, f32 norm inputs) -------------
