@@ -54,6 +54,7 @@ class TimedOps:
         self.ev = {k: [] for k in KERNELS}
         self.fl = {k: 0.0 for k in KERNELS}
         self.by = {k: 0.0 for k in KERNELS}  # algorithmic HBM bytes: every operand and the output once
+        self.rt = {k: 0.0 for k in KERNELS}  # sum over launches of max(FLOPs / MFMA peak, bytes / HBM peak): seconds
         self.attn_big = ([], 0.0)  # (events, flops) of the self-attention launches with Nq == Nk >= 9216
 
     def __getattr__(self, k):
@@ -70,8 +71,10 @@ class TimedOps:
         self.fl[fam] += flops
         esz = lambda t: t.numel() * t.element_size()
         out = y[0] if isinstance(y, tuple) else y
-        self.by[fam] += (sum(esz(t) for t in list(a) + list(kw.values()) if torch.is_tensor(t) and t.numel() > 4096)
-                         + (esz(out) if torch.is_tensor(out) and kw.get("out") is None else 0.0))
+        nbytes = (sum(esz(t) for t in list(a) + list(kw.values()) if torch.is_tensor(t) and t.numel() > 4096)
+                  + (esz(out) if torch.is_tensor(out) and kw.get("out") is None else 0.0))
+        self.by[fam] += nbytes
+        self.rt[fam] += max(flops / (MFMA_PEAK_TFLOPS * 1e12), nbytes / 8e12)
         return y, (e0, e1)
 
     def gemm(self, a, w, *args, **kw):
@@ -125,7 +128,8 @@ class TimedOps:
         out = {}
         for fam in KERNELS:
             ms = sum(a.elapsed_time(b) for a, b in self.ev[fam])
-            out[fam] = {"ms": ms, "launches": len(self.ev[fam]), "flops": self.fl[fam], "bytes": self.by[fam]}
+            out[fam] = {"ms": ms, "launches": len(self.ev[fam]), "flops": self.fl[fam], "bytes": self.by[fam],
+                        "roofline_s": self.rt[fam]}
         ev, fl = self.attn_big
         big = {"ms": sum(a.elapsed_time(b) for a, b in ev), "launches": len(ev), "flops": fl}
         return out, big
@@ -276,6 +280,8 @@ def main():
                           "tflops": tf, "frac_of_peak": tf / MFMA_PEAK_TFLOPS,
                           # the same launches against the OTHER roofline: algorithmic bytes (operands + output once)
                           "algorithmic_TBps": tbs, "frac_of_hbm_8TBps": tbs / 8.0,
+                          # per-launch roofline: every launch priced at max(FLOPs / 2.5 PF, bytes / 8 TB/s)
+                          "frac_of_per_launch_roofline": (v["roofline_s"] / (v["ms"] * 1e-3)) if v["ms"] > 0 else 0.0,
                           "share_of_step_time": (v["ms"] * 1e-3 / 2.0) / step_s}
         return {"res": res, "latent": [T, h, w], "steps": steps, "elapsed": elapsed, "step_s": step_s,
                 "families": fam_out, "raw": fams, "attn_big": big, "x": x, "ins": ins}
@@ -353,6 +359,7 @@ def main():
                     "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
                     "hbm_view": {"achieved": r["families"][fam]["algorithmic_TBps"], "peak": 8.0, "unit": "TB/s",
                                  "frac": r["families"][fam]["frac_of_hbm_8TBps"],
+                                 "frac_of_per_launch_roofline": r["families"][fam]["frac_of_per_launch_roofline"],
                                  "note": "algorithmic bytes of the same launches / the same time: the family mixes "
                                          "MFMA-bound and HBM-bound shapes (DESIGN.md section 3)"},
                     "launches": v["launches"], "avg_launch_ms": v["ms"] / max(1, v["launches"]),

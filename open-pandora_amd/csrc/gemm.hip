@@ -1514,7 +1514,9 @@ static bool prefer_ring(int amode, const GemmParams& p) {
   const int64_t cu = num_cus();
   const double eff_ring = (double)nwork / (double)(((nwork + cu - 1) / cu) * cu);
   const double eff_two = (double)nwork / (double)(((nwork + 2 * cu - 1) / (2 * cu)) * 2 * cu);
-  if (amode == A_CONVT3) return eff_ring > eff_two + 0.05 || (nwork <= cu && nwork >= cu / 2);
+  // (temporal convs: ties go to the ring kernel - 2-8 % faster at M = 10240 .. 147456, tools/shape_profile.py with
+  // PANDORA_GEMM_RING=0/2, profiles/r02/kernel_choice_ab.txt)
+  if (amode == A_CONVT3) return eff_ring + 0.05 >= eff_two || (nwork <= cu && nwork >= cu / 2);
   if (nwork <= cu) return true;  // one tile per CU: the 2-stage kernel would be round-trip-bound
   if (amode == A_CONV3X3_FAST) return eff_ring >= eff_two;  // long K loops: ties go to the faster steady state
   return (p.M <= 2560 && p.splits == 1) || eff_ring > eff_two + 0.05;

@@ -122,7 +122,9 @@ class _SegmentedForward:
 
     def _begin(self):
         self._g = torch.cuda.CUDAGraph()
-        self._ctx = torch.cuda.graph(self._g, pool=self._pool, stream=self._side)
+        # thread-local capture mode: the process group's watchdog thread polls events of the exchanges just issued while
+        # the next segment is being captured; under the default (global) mode its calls would invalidate the capture
+        self._ctx = torch.cuda.graph(self._g, pool=self._pool, stream=self._side, capture_error_mode="thread_local")
         self._ctx.__enter__()
 
     def _end(self):
