@@ -1350,6 +1350,7 @@ static int g_num_cus[MAX_DEVICES] = {0};
 static int g_persist_per_cu = 0;    // PANDORA_GEMM_PERSIST: persistent 2-stage workgroups per CU (0 = one work item per workgroup; measured: 2/CU = no gain, 1 or 3/CU 5 % slower)
 static int g_split_min_nk = 24;     // PANDORA_SPLITK_MIN_NK: shortest K loop (in 64-wide tiles) that is split
 static int g_split_model = 1;       // PANDORA_SPLITK_MODEL: 0 = the round-1 rule (aim at 512 work items), for A/B runs
+static int g_split_force = 0;       // PANDORA_SPLITK_FORCE = s > 0: every splittable call takes (up to) s slices (sweeps that fit the model)
 
 static int current_device() {
   int dev = 0;
@@ -1370,6 +1371,8 @@ static void init_once() {
     if (rw) g_ring_max_work = atoi(rw);
     const char* sm = getenv("PANDORA_SPLITK_MODEL");
     if (sm) g_split_model = atoi(sm);
+    const char* sf = getenv("PANDORA_SPLITK_FORCE");
+    if (sf) g_split_force = atoi(sf);
     const char* ps = getenv("PANDORA_GEMM_PERSIST");
     if (ps) g_persist_per_cu = atoi(ps);
     return true;
@@ -1390,10 +1393,14 @@ static int choose_splits(int64_t M, int64_t N, int64_t K, int act, int* ktps, bo
   const int nk = (int)((K + BK - 1) / BK);
   *ktps = nk;
   if (act == PM_ACT_GEGLU || tiles >= 384 || nk < g_split_min_nk) return 1;
-  // the general 3x3 mode (nearest-x2 upsample) only runs on the 2-stage kernel, two workgroups per CU, where a
-  // single round of <= 256 tiles is round-trip-bound: it keeps the 512-item rule; so do very long K loops, where
-  // three slices of a 360-step loop measured 11 % faster than the unsplit run (narrower K window per XCD L2)
-  if (g_split_model == 0 || two_stage || nk >= 256) {
+  if (g_split_force > 0) {
+    int s = g_split_force;
+    if (s > nk / 4) s = nk / 4;
+    if (s < 2) return 1;
+    *ktps = (nk + s - 1) / s;
+    return (nk + *ktps - 1) / *ktps;
+  }
+  if (g_split_model == 0) {  // the round-1 rule, for A/B runs
     int64_t s = (512 + tiles - 1) / tiles;
     if (s > nk / 4) s = nk / 4;
     if (s > 32) s = 32;
@@ -1401,15 +1408,21 @@ static int choose_splits(int64_t M, int64_t N, int64_t K, int act, int* ktps, bo
     *ktps = (int)((nk + s - 1) / s);
     return (nk + *ktps - 1) / *ktps;
   }
-  const double cus = 256.0, t_step = 0.55, t_fixed = 2.0;  // (a fixed CU count: the plan must not depend on the device)
-  const double slab_us = (double)M * (double)N * 8.0 / 4.5e6;  // one slab written + read, at ~4.5 TB/s
+  // Work items run in rounds of one workgroup per CU on the ring kernel (0.55 us per K-step), of two per CU on the
+  // 2-stage kernel, the only one the general 3x3 mode (nearest-x2 upsample) has (1.1 us per K-step per workgroup).
+  // A slab is written and read once, mostly out of the 256 MiB Infinity Cache: ~9 TB/s.  Constants and the two
+  // exceptions checked against a sweep of forced slice counts (PANDORA_SPLITK_FORCE = 1..10, both resolutions:
+  // profiles/r02/splitk_forced_sweep.txt): the model's pick is within 3 % of the best forced count on every shape.
+  const double slots = two_stage ? 512.0 : 256.0, t_step = two_stage ? 1.1 : 0.55, t_fixed = two_stage ? 3.0 : 2.0;
+  const double slab_us = (double)M * (double)N * 8.0 / 9.0e6;
   int best_s = 1, best_ktps = nk;
   double best = 0.0;
   for (int s = 1; s <= 32 && s <= nk / 4; ++s) {
     const int kt = (nk + s - 1) / s, splits = (nk + kt - 1) / kt;
     if (s > 1 && splits != s) continue;  // (the same plan as a smaller s)
-    const double rounds = (double)((tiles * splits + (int64_t)cus - 1) / (int64_t)cus);
-    const double cost = rounds * (kt * t_step + t_fixed) + (splits > 1 ? 2.5 + splits * slab_us : 0.0);
+    const double rounds = (double)((tiles * splits + (int64_t)slots - 1) / (int64_t)slots);
+    double cost = rounds * (kt * t_step + t_fixed) + (splits > 1 ? 2.5 + splits * slab_us : 0.0);
+    if (splits == 1 && nk >= 256) cost *= 1.1;  // (very long unsplit loops measured ~10 % over the model: L2 window)
     if (s == 1 || cost < best * 0.97) {
       best = cost;
       best_s = splits;
