@@ -306,7 +306,7 @@ static int ln_choose_nsplit(int64_t M, int64_t N, int64_t K, int act, int* nbw_o
   const int rb = ln_gemm_rb(K);
   const int64_t bmp = rb * 16, nb = N / 32;
   const int64_t panels = (M + bmp - 1) / bmp;
-  const double prologue = 13000.0;
+  const double prologue = 20000.0;
   const double per_block = act == PM_ACT_GEGLU ? 10800.0 : 13000.0;
   const int64_t cus = ln_num_cus(), slots = 2 * cus;
   double best = 0.0;
@@ -317,7 +317,7 @@ static int ln_choose_nsplit(int64_t M, int64_t N, int64_t K, int act, int* nbw_o
     const double t_wg = prologue + (double)((nbw + LN_NW - 1) / LN_NW) * per_block;
     const int64_t wgs = panels * s, full = wgs / slots, rem = wgs - full * slots;
     // a last round of at most one workgroup per CU runs its waves alone on their SIMDs
-    const double cost = (double)full * t_wg + (rem == 0 ? 0.0 : (rem <= cus ? 0.6 * t_wg : t_wg));
+    const double cost = (double)full * t_wg + (rem == 0 ? 0.0 : (rem <= cus ? 0.75 * t_wg : t_wg));
     if (best == 0.0 || cost < best * 0.98) {
       best = cost;
       best_s = s;
