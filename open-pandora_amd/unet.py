@@ -554,14 +554,12 @@ class UNetModel(packing.PackedWeights, nn.Module):
         (1, C_out, t_local, h, w) in f32.  In frame-sharded mode x holds this rank's
         frames and `context` is the full-clip context (image tokens are sliced by `fp`)."""
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            # the training seam (model.py:926-942 -> ddpm3d.py:701-706 -> apply_model): the op tables of this
-            # package are forward-only kernels on detached, packed weights - no autograd graph would be built and
-            # loss.backward() would fail (or silently train nothing) far from here
-            raise RuntimeError(
-                "open_pandora_amd.unet.UNetModel is an inference module: called in training mode with autograd "
-                "enabled (WorldModel.training_step reaches the U-Net through LatentDiffusion.p_losses).  Train with the "
-                "reference's eager lvdm UNetModel - the state_dict keys are identical, so the trained weights load "
-                "here - or call under .eval() / torch.no_grad() for inference.")
+            # the training seam (model.py:926-942 -> ddpm3d.py:741-797 -> apply_model): the HIP op table is forward-only
+            # (packed, detached weights), so the graph is walked with differentiable torch ops over the module's own
+            # parameters instead (SURVEY §8(b)); inference - eval() or no_grad - never takes this branch
+            from . import unet_train
+            _unsupported(features_adapter is not None, "features_adapter")
+            return unet_train.forward(self, x, timesteps, context, fs)
         with torch.no_grad():
             return self._forward(x, timesteps, context, features_adapter, fs, **kwargs)
 

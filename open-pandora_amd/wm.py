@@ -1,7 +1,9 @@
 """Caller surfaces of the hot path, with the names / arguments / return layout of the reference's
 world-model driver (model.py), restated around the MI355X path:
 
-  image_guided_synthesis(...)   model.py:703-781   condition assembly, n_samples loop, sampler call
+  DiffusionRunner.image_guided_synthesis(...)   model.py:703-781   the reference's argument list (condition
+                                assembly from `videos` / `diffusion_cond_image`, n_samples loop, sampler call);
+                                `_synthesize` is the factored core on already-embedded conditions
   get_latent_z(...)             model.py:690-701   conditioning-frame tiling to 16 latent frames
   DiffusionRunner.generate(...) model.py:783-816   noise_shape from the conditioning frames
   multi-round stitching         model.py:1094-1129, 1199-1211
@@ -32,13 +34,13 @@ def get_latent_z(encode_first_stage, videos):
 
 
 @torch.no_grad()
-def image_guided_synthesis(diffusion_model, diffusion_conditioning, img_emb, uc_text_emb, uc_img_emb, z_cond,
-                           noise_shape, n_samples=1, ddim_steps=50, ddim_eta=1.0,
-                           unconditional_guidance_scale=1.0, cfg_img=None, fs=None, multiple_cond_cfg=False,
-                           timestep_spacing="uniform", guidance_rescale=0.0, decode_first_stage=None,
-                           sampler=None, **kwargs):
-    """model.py:703-781 with the encoders factored out.  Returns (batch, n_samples, c, t, h, w):
-    decoded frames if `decode_first_stage` is given, else latents."""
+def _synthesize(diffusion_model, diffusion_conditioning, img_emb, uc_text_emb, uc_img_emb, z_cond,
+                noise_shape, n_samples=1, ddim_steps=50, ddim_eta=1.0,
+                unconditional_guidance_scale=1.0, cfg_img=None, fs=None, multiple_cond_cfg=False,
+                timestep_spacing="uniform", guidance_rescale=0.0, decode_first_stage=None,
+                sampler=None, **kwargs):
+    """model.py:703-781 with the encoders factored out (private core of `DiffusionRunner.image_guided_synthesis`).
+    Returns (batch, n_samples, c, t, h, w): decoded frames if `decode_first_stage` is given, else latents."""
     if multiple_cond_cfg:
         # SURVEY §8f row 4.  The reference's DDIMSampler_multicond cannot run on this model either: its
         # make_schedule (ddim_multiplecond.py:40) calls np.sqrt on the bf16 alphas_cumprod buffer that
@@ -101,20 +103,42 @@ class DiffusionRunner:
         self.sampler = DDIMSampler(diffusion_model)
 
     @torch.no_grad()
+    def image_guided_synthesis(self, diffusion_conditioning, videos, diffusion_cond_image, noise_shape, n_samples=1,
+                               ddim_steps=50, ddim_eta=1., unconditional_guidance_scale=1.0, cfg_img=None, fs=None,
+                               multiple_cond_cfg=False, loop=False, gfi=False, timestep_spacing='uniform',
+                               guidance_rescale=0.0, **kwargs):
+        """WorldModel.image_guided_synthesis with the reference's argument list (model.py:703-704):
+        diffusion_conditioning (b, 77, 1024) from the LLM side, `videos` (b, 3, 1|4, H, W) conditioning frames
+        (-> c_concat through get_latent_z, :717-719), `diffusion_cond_image` (b, 3, H, W) (-> image tokens, :710-712;
+        the zero image's tokens for the unconditional branch, :728-729), noise_shape [b, 4, T, h, w].  `loop` and
+        `gfi` are accepted and unused, exactly as in the reference's body (they never reach the sampler there
+        either: they are named parameters, not **kwargs).  -> (b, n_samples, c, T, H, W)."""
+        del loop, gfi
+        z = get_latent_z(self.encode_first_stage, videos)
+        img_emb = self.embed_image(diffusion_cond_image)
+        uc_text = uc_img_emb = None
+        if unconditional_guidance_scale != 1.0:
+            uc_text = self.uncond_text_emb  # uncond_type "empty_seq": the text encoder's tokens of "" (:723-725)
+            uncond = getattr(self.embed_image, "uncond", None)  # ImageContext caches the zero-image tokens
+            uc_img_emb = (uncond(diffusion_cond_image) if uncond
+                          else self.embed_image(torch.zeros_like(diffusion_cond_image)))
+        return _synthesize(self.diffusion_model, diffusion_conditioning, img_emb, uc_text, uc_img_emb, z, noise_shape,
+                           n_samples=n_samples, ddim_steps=ddim_steps, ddim_eta=ddim_eta,
+                           unconditional_guidance_scale=unconditional_guidance_scale, cfg_img=cfg_img, fs=fs,
+                           multiple_cond_cfg=multiple_cond_cfg, timestep_spacing=timestep_spacing,
+                           guidance_rescale=guidance_rescale, sampler=self.sampler,
+                           decode_first_stage=self.decode_first_stage, **kwargs)
+
+    @torch.no_grad()
     def generate(self, diffusion_conditioning, diffusion_pixel_values, diffusion_cond_image, **generate_kwargs):
         """diffusion_conditioning (1, 77, 1024) from the LLM side; diffusion_pixel_values (3, 1|4, H, W)
-        conditioning frames; diffusion_cond_image (1, 3, H, W).  -> (1, n_samples, c, 16, h, w)."""
+        conditioning frames; diffusion_cond_image (1, 3, H, W).  -> (1, n_samples, c, 16, h, w)  (model.py:783-816)."""
         kw = dict(self.GENERATE_KWARGS)
         kw.update(generate_kwargs)
         h, w = diffusion_pixel_values.shape[-2:]
-        z = get_latent_z(self.encode_first_stage, diffusion_pixel_values[None, ...])
-        img_emb = self.embed_image(diffusion_cond_image)
-        uncond = getattr(self.embed_image, "uncond", None)  # ImageContext caches the zero-image tokens
-        uc_img_emb = uncond(diffusion_cond_image) if uncond else self.embed_image(torch.zeros_like(diffusion_cond_image))
         T = self.diffusion_model.temporal_length
-        return image_guided_synthesis(self.diffusion_model, diffusion_conditioning[-1:], img_emb, self.uncond_text_emb,
-                                      uc_img_emb, z, [1, 4, T, h // 8, w // 8], sampler=self.sampler,
-                                      decode_first_stage=self.decode_first_stage, **kw)
+        return self.image_guided_synthesis(diffusion_conditioning[-1:], diffusion_pixel_values[None, ...],
+                                           diffusion_cond_image, [1, 4, T, h // 8, w // 8], **kw)
 
     @staticmethod
     def stitch_rounds(videos):

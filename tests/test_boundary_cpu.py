@@ -5,7 +5,8 @@
   the REFERENCE DDIMSampler (ddim.py:66) drives it: result == the goldens captured from the all-reference run;
 * the converse: the product DDIMSampler around the all-reference shell;
 * reloading through the parent after a forward re-packs the kernel-side weights (ADVICE r01);
-* the training seam fails loudly; the documented ctypes stub matches capi.py and the header."""
+* the training seam: gradients equal the reference module's, an optimizer step re-packs the kernel-side weights;
+  the documented ctypes stub matches capi.py and the header."""
 import os
 import re
 
@@ -87,16 +88,78 @@ def test_parent_reload_inplace_edit_and_cast_repack_the_weights():
     assert m._packed is None
 
 
-def test_training_seam_fails_loudly():
-    m = UNetModel(**dict(RH_KW, model_channels=64)).bind(TorchOps())
-    m.load_state_dict(synth.synth_state_dict(m, seed=3))
+def _no_dropout(m):
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0  # (TemporalConvBlock hard-codes p = 0.1, openaimodel3d.py:266-273: not comparable draw by draw)
+    return m
+
+
+def _train_inputs(batch):
     ins, _, _ = gr.sampler_inputs(8, 8)
     x = torch.cat([ins["x_T"], ins["c_concat"]], 1)
+    ctx = ins["c_crossattn"]
+    if batch > 1:  # a second, different clip
+        g = torch.Generator().manual_seed(77)
+        x = torch.cat([x, torch.randn(x.shape, generator=g)], 0)
+        ctx = torch.cat([ctx, torch.randn(ctx.shape, generator=g)], 0)
+    t = torch.tensor([500, 120][:batch])
+    fs = torch.tensor([15, 7][:batch])
+    return x, t, ctx, fs
+
+
+@needs_ref
+@pytest.mark.parametrize("batch", [1, 2])
+def test_training_seam_gradients_equal_the_reference_module(batch):
+    """SURVEY §8(b) / model.py:926-942: in training mode with autograd on, the product UNetModel builds an autograd graph
+    over its OWN parameters; loss and every parameter gradient equal the reference module's (f32, dropout off)."""
+    ref = _no_dropout(rh.reference_unet(model_channels=64)).train()
+    m = _no_dropout(UNetModel(**dict(RH_KW, model_channels=64))).train()  # note: NOT bound to any op table
+    sd = synth.synth_state_dict(m, seed=3)
+    ref.load_state_dict(sd)
+    m.load_state_dict(sd)
+    x, t, ctx, fs = _train_inputs(batch)
+    target = torch.randn(batch, 4, 16, 8, 8, generator=torch.Generator().manual_seed(5))
+    grads = []
+    for mod in (ref, m):
+        mod.zero_grad()
+        y = mod(x, t, context=ctx, fs=fs)
+        loss = torch.nn.functional.mse_loss(y, target)  # (the 'l2' loss of ddpm3d.py:258-273 on the v-target)
+        loss.backward()
+        grads.append((y.detach(), loss.item(), {k: p.grad.clone() for k, p in mod.named_parameters()}))
+    (y0, l0, g0), (y1, l1, g1) = grads
+    assert rel(y1, y0) < 1e-5 and abs(l1 - l0) < 1e-5 * abs(l0)
+    assert g0.keys() == g1.keys()
+    worst = max(rel(g1[k], g0[k]) for k in g0 if g0[k].norm() > 0)
+    assert worst < 1e-5, worst
+    assert all(g1[k].abs().max() > 0 for k in g1)  # every parameter is reached (incl. the zero-init modules, overwritten by synth)
+
+
+def test_training_seam_trains_and_inference_stays_on_the_op_table():
+    """One AdamW step through the seam (configure_optimizers, model.py:951-962) lowers the loss, re-packs the kernel-side
+    weights, and eval() / no_grad calls still run on the bound op table (or raise when none is bound)."""
+    m = _no_dropout(UNetModel(**dict(RH_KW, model_channels=64)))
+    m.load_state_dict(synth.synth_state_dict(m, seed=3))
+    x, t, ctx, fs = _train_inputs(1)
+    m.eval()
+    with pytest.raises(RuntimeError, match="bind"):  # inference without an op table: loud, no eager fallback
+        m(x, t, context=ctx, fs=fs)
+    m.bind(TorchOps())
+    y_inf = m(x, t, context=ctx, fs=fs)
+    assert not y_inf.requires_grad
     m.train()
-    with pytest.raises(RuntimeError, match="inference module"):
-        m(x, torch.tensor([500]), context=ins["c_crossattn"], fs=torch.tensor([15]))
-    with torch.no_grad():  # (what WorldModel.generate does, model.py:783)
-        assert torch.isfinite(m(x, torch.tensor([500]), context=ins["c_crossattn"], fs=torch.tensor([15]))).all()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4)
+    target = torch.zeros(1, 4, 16, 8, 8)
+    y = m(x, t, context=ctx, fs=fs)
+    assert y.requires_grad and rel(y.detach(), y_inf) < 2e-5  # same function as the inference graph
+    loss0 = torch.nn.functional.mse_loss(y, target)
+    loss0.backward()
+    epoch = m._pack_epoch
+    opt.step()
+    with torch.no_grad():  # (what WorldModel.generate does, model.py:783): op table again, with the updated weights
+        y2 = m(x, t, context=ctx, fs=fs)
+    assert m._pack_epoch > epoch
+    assert torch.nn.functional.mse_loss(y2, target) < loss0
 
 
 @pytest.mark.parametrize("L,tag", gr.UNET_CTX_CASES)

@@ -55,4 +55,4 @@ def test_multicond_sampler_is_dead_in_the_reference():
     with pytest.raises(TypeError, match="BFloat16"):
         CPUSampler(m).make_schedule(5, "uniform_trailing", 0.0, verbose=False)
     with pytest.raises(NotImplementedError, match="multiple_cond_cfg"):
-        wm.image_guided_synthesis(None, None, None, None, None, None, (1, 4, 16, 8, 8), multiple_cond_cfg=True)
+        wm._synthesize(None, None, None, None, None, None, (1, 4, 16, 8, 8), multiple_cond_cfg=True)
