@@ -15,8 +15,13 @@ objects:
   roofline_attention  the spatial self-attention at N = 9216 tokens (72x128 latent, 16 frames x 5 heads),
                       FLOPs 4 N^2 64 heads frames per launch (attention.py:81-144), in the 576x1024 loop;
   cpu_baseline        the CPU oracle (f32 eager restatement of the reference) on the host cores.
-`roofline.traffic` is null: HBM-side bytes come from separate rocprofv3 --pmc passes (profiles/r02/), never from
-this run.
+  roofline.dominant_kernel   the single KERNEL (not family) with the largest summed time, with its own fraction;
+  compute_scaling     one rank's share of a frame-sharded step measured on THIS GPU: the U-Net forward (graph replay) on
+                      clips of T/N frames for N = 2, 4, 8 - the compute-side bound of the N-GPU speed-up.
+`share_of_sequential_step` are shares of the EAGER, single-stream step the family times were taken in (they sum to 1 with
+`other`); the timed steps replay a two-stream graph and are shorter than that sum.  `roofline.traffic` comes from the
+committed PMC summary (profiles/r03/pmc_traffic.json, separate rocprofv3 --pmc passes) only when that file was
+produced with the library sources of this run (digest match), else null - never a stale constant.
 """
 import argparse
 import json
@@ -56,6 +61,7 @@ class TimedOps:
         self.by = {k: 0.0 for k in KERNELS}  # algorithmic HBM bytes: every operand and the output once
         self.rt = {k: 0.0 for k in KERNELS}  # sum over launches of max(FLOPs / MFMA peak, bytes / HBM peak): seconds
         self.attn_big = ([], 0.0)  # (events, flops) of the self-attention launches with Nq == Nk >= 9216
+        self.kern = {}  # dense family by KERNEL: name -> [events, flops]
 
     def __getattr__(self, k):
         return getattr(self._ops, k)
@@ -77,9 +83,28 @@ class TimedOps:
         self.rt[fam] += max(flops / (MFMA_PEAK_TFLOPS * 1e12), nbytes / 8e12)
         return y, (e0, e1)
 
+    def _kern(self, name, ev, flops):
+        k = self.kern.setdefault(name, [[], 0.0])
+        k[0].append(ev)
+        k[1] += flops
+
     def gemm(self, a, w, *args, **kw):
-        r = self._timed("gemm", 2.0 * a.shape[0] * w.shape[0] * w.shape[1], self._ops.gemm, a, w, *args, **kw)
-        return r[0] if self.enabled else r
+        fl = 2.0 * a.shape[0] * w.shape[0] * w.shape[1]
+        r = self._timed("gemm", fl, self._ops.gemm, a, w, *args, **kw)
+        if not self.enabled:
+            return r
+        # which kernel the library's own plan gives this call (pm_gemm_kernel_choice mirrors pm_gemm's decision)
+        o = self._ops
+        f32_loader = a.dtype == torch.float32 and not o.presplit
+        act = kw.get("act", args[2] if len(args) > 2 else "none")
+        k_eff = a.shape[1] * (2 if (kw.get("split_a") and a.dtype == torch.float32 and o.presplit) else 1)
+        k_eff += (-k_eff) % 64
+        ch = o.lib.pm_gemm_kernel_choice(a.shape[0], w.shape[0], k_eff, 2 if act == "geglu" else 0,
+                                         1 if f32_loader else 0, o.ws_bytes)
+        name = ("gemm_kernel<A_DENSE, f32 operand> (register-staged)" if f32_loader else
+                "gemm_ring_kernel<A_DENSE>" if ch == 1 else "gemm_kernel<A_DENSE> (128x128, 2 LDS stages, 2 workgroups/CU)")
+        self._kern(name, r[1], fl)
+        return r[0]
 
     def ln_gemm(self, x, gamma, beta, w, *args, **kw):
         # LayerNorm + projection: ONE launch (pm_ln_gemm) at the 320-wide level, counted with its GEMM FLOPs (the
@@ -87,8 +112,12 @@ class TimedOps:
         if not self._ops.fused_ln or not self._ops.lib.pm_ln_gemm_supported(x.shape[0], w.shape[0], x.shape[1],
                                                                              2 if kw.get("act") == "geglu" else 0):
             return self.gemm(self._ops.layernorm(x, gamma, beta), w, *args, **kw)
-        r = self._timed("gemm", 2.0 * x.shape[0] * w.shape[0] * w.shape[1], self._ops.ln_gemm, x, gamma, beta, w, *args, **kw)
-        return r[0] if self.enabled else r
+        fl = 2.0 * x.shape[0] * w.shape[0] * w.shape[1]
+        r = self._timed("gemm", fl, self._ops.ln_gemm, x, gamma, beta, w, *args, **kw)
+        if not self.enabled:
+            return r
+        self._kern("ln_gemm_kernel (LayerNorm + projection panel kernel)", r[1], fl)
+        return r[0]
 
     def conv3x3(self, x, wp, bias, F, H, W, **kw):
         hv, wv = (2 * H, 2 * W) if kw.get("upsample") else (H, W)
@@ -132,7 +161,9 @@ class TimedOps:
                         "roofline_s": self.rt[fam]}
         ev, fl = self.attn_big
         big = {"ms": sum(a.elapsed_time(b) for a, b in ev), "launches": len(ev), "flops": fl}
-        return out, big
+        kern = {name: {"ms": sum(a.elapsed_time(b) for a, b in evs), "launches": len(evs), "flops": kfl}
+                for name, (evs, kfl) in self.kern.items()}
+        return out, big, kern
 
 
 def cpu_baseline(unet, res, ins):
@@ -154,6 +185,66 @@ def cpu_baseline(unet, res, ins):
             "sample": f"1 of the 2 U-Net forwards of one CFG DDIM step at {res} (f32 oracle, {dt:.1f} s), x2 per step"}
 
 
+def committed_traffic(res):
+    """HBM-side bytes of the dominant kernels from the committed PMC summary (separate rocprofv3 --pmc passes, gfx950
+    FETCH_SIZE correction applied there) - only when it was taken with the library sources of THIS run."""
+    path = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
+    try:
+        from open_pandora_amd import build as _b
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("lib_digest") != _b._digest():
+            return None
+        return t.get(res)
+    except (OSError, ValueError):
+        return None
+
+
+def compute_scaling(pm_of, unet, ops, dev, reps=6):
+    """One rank's kernels of a frame-sharded step, on this one GPU (VERDICT r02 #3a): the U-Net forward, replayed as a
+    HIP graph, on clips of 16 / N frames.  N-way frame shards run exactly these shapes per rank (the temporal blocks
+    re-shard to all 16 frames x P/N pixels: the same token count), so t(16) / t(16/N) bounds the speed-up of the
+    compute side; exchanges come on top."""
+    from open_pandora_amd import factory, synth
+    from open_pandora_amd.ddim import _ForwardGraph
+    out = {}
+    for res in ("320x512", "576x1024"):
+        h, w = factory.RESOLUTIONS[res]["image_size"]
+        pm = pm_of(res)
+        row = {}
+        for n in (1, 2, 4, 8):
+            t = T // n
+            ins = synth.synth_inputs(h, w, t, seed=123)
+            cond = {"c_crossattn": [ins["c_crossattn"].to(dev)], "c_concat": [ins["c_concat"].to(dev)]}
+            uc = {"c_crossattn": [ins["uc_crossattn"].to(dev)], "c_concat": [ins["c_concat"].to(dev)]}
+            x, ts, fs = ins["x_T"].to(dev), torch.full((1,), 500, device=dev, dtype=torch.long), torch.tensor([15], device=dev)
+            entry = {"frames": t}
+            for tag, u in (("one_forward_ms", None), ("cfg_pair_two_streams_ms", uc)):
+                g = _ForwardGraph(pm, x, ts, cond, u, fs, {})
+                g(x, ts)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    g(x, ts)
+                torch.cuda.synchronize()
+                entry[tag] = 1e3 * (time.perf_counter() - t0) / reps
+                del g
+            row[str(n)] = entry
+        base1, base2 = row["1"]["one_forward_ms"], row["1"]["cfg_pair_two_streams_ms"]
+        for n, e in row.items():
+            e["speedup_one_forward"] = base1 / e["one_forward_ms"]
+            e["speedup_cfg_pair"] = base2 / e["cfg_pair_two_streams_ms"]
+        # the two 8-GPU decompositions of frame_parallel.make_hybrid, compute side only (1-GPU step = cfg pair on 16 frames)
+        row["projection_8gpu"] = {
+            "cfg_pair_x_4_frame_shards": base2 / row["4"]["one_forward_ms"],
+            "8_frame_shards_both_branches_per_rank": base2 / row["8"]["cfg_pair_two_streams_ms"],
+            "note": "1-GPU step time / one rank's kernel time at its shard size: an upper bound, exchanges not included"}
+        row["projection_4gpu"] = {"cfg_pair_x_2_frame_shards": base2 / row["2"]["one_forward_ms"]}
+        row["projection_2gpu"] = {"cfg_pair": base2 / row["1"]["one_forward_ms"]}
+        out[res] = row
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,6 +255,9 @@ def main():
                     help="kernel-work runs: measure one resolution (the driver line always carries both)")
     ap.add_argument("--res", default=None, help=argparse.SUPPRESS)  # (round-1 spelling of --only)
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
+    ap.add_argument("--emulate-shard", default="auto", choices=["auto", "off", "only"],
+                    help="compute_scaling: the U-Net forward on 16/N-frame clips (N = 2, 4, 8) on this one GPU; "
+                         "'only' prints just that object")
     ap.add_argument("--fp8-attention", action="store_true",
                     help="spatial self-attention on pm_attention_fp8 (block-scaled e4m3 MFMA): BASELINE configs[4]")
     ap.add_argument("--multiround", type=int, default=0,
@@ -200,7 +294,7 @@ def main():
     mode = "1 GPU"
     if world > 1:
         from open_pandora_amd.frame_parallel import make_hybrid
-        fp, cfgp = make_hybrid(T)
+        fp, cfgp = make_hybrid(T, ops=ops)
         unet.bind(ops, fp)
         fw = 1 if fp is None else fp.world
         mode = (f"{'cond/uncond branch pair x ' if cfgp is not None else ''}{fw}-way frame shards "
@@ -216,16 +310,25 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def run_resolution(res, steps, warmup):
-        h, w = factory.RESOLUTIONS[res]["image_size"]
-        if res == "320x512":
-            pm = pm0
-        else:  # same U-Net behind the other yaml's shell (base_scale of the dynamic rescale, image size)
+    _pm = {"320x512": pm0}
+
+    def pm_of(res):
+        if res not in _pm:  # same U-Net behind the other yaml's shell (base_scale of the dynamic rescale, image size)
             r = dict(factory.RESOLUTIONS[res])
             r.pop("default_fs")
-            pm = LatentVisualDiffusion(unet, linear_start=0.00085, linear_end=0.012, timesteps=1000,
-                                       parameterization="v", rescale_betas_zero_snr=True, conditioning_key="hybrid",
-                                       use_dynamic_rescale=True, scale_factor=0.18215, channels=4, **r)
+            _pm[res] = LatentVisualDiffusion(unet, linear_start=0.00085, linear_end=0.012, timesteps=1000,
+                                             parameterization="v", rescale_betas_zero_snr=True, conditioning_key="hybrid",
+                                             use_dynamic_rescale=True, scale_factor=0.18215, channels=4, **r)
+        return _pm[res]
+
+    if a.emulate_shard == "only":
+        assert world == 1
+        print(json.dumps({"compute_scaling": compute_scaling(pm_of, unet, ops, dev), "dtype": a.dtype}), flush=True)
+        return
+
+    def run_resolution(res, steps, warmup):
+        h, w = factory.RESOLUTIONS[res]["image_size"]
+        pm = pm_of(res)
         ins = synth.synth_inputs(h, w, T, seed=123)
         cond = {"c_crossattn": [ins["c_crossattn"].to(dev)], "c_concat": [ins["c_concat"].to(dev)]}
         uc = {"c_crossattn": [ins["uc_crossattn"].to(dev)], "c_concat": [ins["c_concat"].to(dev)]}
@@ -262,10 +365,14 @@ def main():
         run(1, warmup + steps)
         ops.reset()
         ops.enabled = True
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
         run(2, warmup + steps + 1)
+        s1.record()
         torch.cuda.synchronize()
         ops.enabled = False
-        fams, big = ops.summary()
+        seq_step_ms = s0.elapsed_time(s1) / 2.0  # one eager, single-stream step (what the family times are parts of)
+        fams, big, kern = ops.summary()
         if world > 1:
             tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -282,9 +389,14 @@ def main():
                           "algorithmic_TBps": tbs, "frac_of_hbm_8TBps": tbs / 8.0,
                           # per-launch roofline: every launch priced at max(FLOPs / 2.5 PF, bytes / 8 TB/s)
                           "frac_of_per_launch_roofline": (v["roofline_s"] / (v["ms"] * 1e-3)) if v["ms"] > 0 else 0.0,
-                          "share_of_step_time": (v["ms"] * 1e-3 / 2.0) / step_s}
+                          "share_of_sequential_step": (v["ms"] / 2.0) / seq_step_ms}
+        fam_out["other"] = {"ms_per_step": seq_step_ms - sum(v["ms"] for v in fams.values()) / 2.0,
+                            "share_of_sequential_step": 1.0 - sum(v["ms"] for v in fams.values()) / 2.0 / seq_step_ms,
+                            "what": "GroupNorm / LayerNorm / temporal attention / split16 / split-K reduce / DDIM update "
+                                    "and the gaps of an eagerly issued step"}
         return {"res": res, "latent": [T, h, w], "steps": steps, "elapsed": elapsed, "step_s": step_s,
-                "families": fam_out, "raw": fams, "attn_big": big, "x": x, "ins": ins}
+                "seq_step_ms": seq_step_ms, "families": fam_out, "raw": fams, "attn_big": big, "kern": kern, "x": x,
+                "ins": ins}
 
     results = {}
     if only in (None, "320x512"):
@@ -355,15 +467,27 @@ def main():
             fam = max(r["raw"], key=lambda k: r["raw"][k]["ms"])
             v = r["raw"][fam]
             ach = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
+            dom = None
+            if r["kern"]:
+                kn = max(r["kern"], key=lambda k: r["kern"][k]["ms"])
+                kv = r["kern"][kn]
+                ktf = kv["flops"] / (kv["ms"] * 1e-3) / 1e12 if kv["ms"] > 0 else 0.0
+                dom = {"kernel": kn, "ms_per_step": kv["ms"] / 2.0, "launches_per_step": kv["launches"] // 2,
+                       "achieved": ktf, "unit": "TFLOP/s", "frac": ktf / MFMA_PEAK_TFLOPS,
+                       "share_of_sequential_step": kv["ms"] / 2.0 / r["seq_step_ms"],
+                       "all_dense_kernels": {n: {"ms_per_step": x["ms"] / 2.0, "tflops": (x["flops"] / (x["ms"] * 1e-3) / 1e12
+                                                                                        if x["ms"] > 0 else 0.0)}
+                                             for n, x in r["kern"].items()}}
             return {"bound": "mfma", "kernel": KERNELS[fam], "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": committed_traffic(r["res"]),
+                    "dominant_kernel": dom, "sequential_step_ms": r["seq_step_ms"],
                     "hbm_view": {"achieved": r["families"][fam]["algorithmic_TBps"], "peak": 8.0, "unit": "TB/s",
                                  "frac": r["families"][fam]["frac_of_hbm_8TBps"],
                                  "frac_of_per_launch_roofline": r["families"][fam]["frac_of_per_launch_roofline"],
                                  "note": "algorithmic bytes of the same launches / the same time: the family mixes "
                                          "MFMA-bound and HBM-bound shapes (DESIGN.md section 3)"},
                     "launches": v["launches"], "avg_launch_ms": v["ms"] / max(1, v["launches"]),
-                    "share_of_step_time": r["families"][fam]["share_of_step_time"],
+                    "share_of_sequential_step": r["families"][fam]["share_of_sequential_step"],
                     "chosen_by": "largest summed HIP-event time among the MFMA kernel families of this run",
                     "families": r["families"]}
 
@@ -407,6 +531,8 @@ def main():
             out["config"]["attention"] = "fp8 (e4m3) operands on v_mfma_scale_f32_32x32x64_f8f6f4 for the spatial self-attention"
         if multi is not None:
             out["config4_multiround"] = multi
+        if a.emulate_shard == "auto" and world == 1 and only is None:
+            out["compute_scaling"] = compute_scaling(pm_of, unet, ops, dev)
         if a.cpu_baseline == "auto" and world == 1:
             out["cpu_baseline"] = cpu_baseline(unet, res, head["ins"])
         print(json.dumps(out), flush=True)

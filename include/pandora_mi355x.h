@@ -107,6 +107,12 @@ size_t pm_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int act);
  * pm_groupnorm_finalize_colstats takes mtiles = ceil(M/rows). */
 int pm_gemm_colstats_rows(int64_t M, int64_t N, int64_t K, int act, size_t workspace_bytes);
 
+/* Measurement aid (bench.py attributes launch times to kernels with it; no call site in the reference): which
+ * kernel a pm_gemm call of this shape runs on, by the library's own plan - 0 = gemm_kernel (128x128 tile, two LDS
+ * stages, two workgroups per CU), 1 = gemm_ring_kernel (wave-specialised 4-stage ring, one workgroup per CU);
+ * negative = PM_E_SHAPE.  `flags` as for pm_gemm, `workspace_bytes` the split-K scratch the call would be given. */
+int pm_gemm_kernel_choice(int64_t M, int64_t N, int64_t K, int act, int flags, size_t workspace_bytes);
+
 /* ------------------------------------------------------------------------------------------------
  * pm_conv2d_3x3: implicit-GEMM 3x3 convolution, padding 1, on channels-last frames.
  * replaces ResBlock in_layers[2] / out_layers[3] (openaimodel3d.py:157,182,221,232), the stem
@@ -303,6 +309,39 @@ int pm_latent_affine(const float* x, const float* W, const float* b, void* y, in
                      int64_t F, int64_t P, float inv_scale, int dtype, void* stream);
 int pm_softmax_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t M, int64_t N,
                     float scale, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Peer mailboxes: the latency-class exchanges of the frame-sharded forward (the 256-byte
+ * (T,H,W)-GroupNorm partial sums of every rank + the boundary frames of the two neighbour ranks in front of each
+ * temporal-conv stage, openaimodel3d.py:258-282) as ONE kernel launch per exchange: direct peer writes over xGMI
+ * into hipIpc-mapped mailboxes, arrival counters at system scope, no RCCL call and no host round trip, so the
+ * launch can sit inside a captured HIP graph.  No counterpart in the reference (its only collective,
+ * lvdm/common.py:8-14, is never called); the bulk frames<->pixels all-to-all stays on RCCL.
+ *   These five are the only entry points that allocate / map memory (pm_peer_create, pm_peer_open) or synchronise
+ *   (pm_peer_create, pm_peer_status); pm_peer_exchange itself follows the conventions at the top of this file.
+ *   pm_peer_mailbox_bytes: size of one rank's mailbox for `world` ranks (<= 16), up to nstat_max partial sums and
+ *     halo frames of up to halo_bytes_max bytes (two slots, alternating by an epoch counter inside the mailbox).
+ *   pm_peer_create: zeroed mailbox on the current device + its 64-byte hipIpc handle (*fine_grained: 1 if the
+ *     allocation is fine-grained device memory, 0 if the runtime only shared plain device memory).
+ *   pm_peer_open / pm_peer_close: map / unmap a peer's mailbox from its handle; pm_peer_destroy frees one's own.
+ *   pm_peer_status: synchronous read of {exchanges completed, error}: error = 1 after a poll timed out (the
+ *     kernel never hangs: it gives up after `timeout_s`, raises the word and lets the stream continue).
+ *   pm_peer_exchange: enqueue one exchange on `stream`.  stats f32 [nstat] -> totals f32 [nstat] = the sum over
+ *     ranks IN RANK ORDER (bitwise identical on every rank).  first / last (both or neither): this rank's first and
+ *     last frame, halo_bytes each (multiple of 16) -> lo_out (the frame before this rank's first, from rank - 1;
+ *     ignored on rank 0) and hi_out (after its last, from rank + 1; ignored on the last rank).  `peers` is a HOST
+ *     array of `world` mapped mailbox pointers (entry `rank` unused).  Every rank of the group must enqueue the same
+ *     sequence of exchanges with the same sizes.
+ */
+size_t pm_peer_mailbox_bytes(int world, int64_t nstat_max, int64_t halo_bytes_max);
+int pm_peer_create(size_t bytes, void** base, void* handle, int* fine_grained);
+int pm_peer_open(const void* handle, void** base);
+int pm_peer_close(void* base);
+int pm_peer_destroy(void* base);
+int pm_peer_status(const void* base, int* epoch, int* error);
+int pm_peer_exchange(void* mine, const void* const* peers, int rank, int world, const float* stats, int64_t nstat,
+                     const void* first, const void* last, int64_t halo_bytes, float* totals, void* lo_out,
+                     void* hi_out, int64_t nstat_max, int64_t halo_bytes_max, double timeout_s, void* stream);
 
 #ifdef __cplusplus
 }

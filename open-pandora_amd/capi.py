@@ -24,6 +24,7 @@ SIGNATURES = {
     "pm_groupnorm_finalize_colstats": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "pm_gemm_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
     "pm_gemm_colstats_rows": (c_int, [c_int64, c_int64, c_int64, c_int, c_size_t]),
+    "pm_gemm_kernel_choice": (c_int, [c_int64, c_int64, c_int64, c_int, c_int, c_size_t]),
     "pm_conv2d_3x3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                               c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int,
                               c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
@@ -67,6 +68,14 @@ SIGNATURES = {
                                  c_float, c_int, c_void_p]),
     "pm_softmax_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_float, c_int,
                                 c_void_p]),
+    "pm_peer_mailbox_bytes": (c_size_t, [c_int, c_int64, c_int64]),
+    "pm_peer_create": (c_int, [c_size_t, c_void_p, c_void_p, c_void_p]),
+    "pm_peer_open": (c_int, [c_void_p, c_void_p]),
+    "pm_peer_close": (c_int, [c_void_p]),
+    "pm_peer_destroy": (c_int, [c_void_p]),
+    "pm_peer_status": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "pm_peer_exchange": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                 c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p]),
 }
 
 _lib = None

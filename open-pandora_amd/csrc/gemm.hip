@@ -1676,6 +1676,19 @@ extern "C" int pm_gemm_colstats_rows(int64_t M, int64_t N, int64_t K, int act, s
   return split ? 16 : 64;
 }
 
+extern "C" int pm_gemm_kernel_choice(int64_t M, int64_t N, int64_t K, int act, int flags, size_t workspace_bytes) {
+  // mirrors pm_gemm's own decision (plan_split + launch<T, A_DENSE>): which kernel a dense call of this shape runs on
+  if (M < 1 || N < 1 || K < BK || (K % BK)) return PM_E_SHAPE;
+  if (flags & PM_FLAG_A_F32) return 0;
+  init_once();
+  GemmParams p{};
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
+  p.ntiles = (int)((N + BN - 1) / BN);
+  static float dummy_ws;  // (only its non-NULLness matters to plan_split)
+  plan_split(p, workspace_bytes ? &dummy_ws : nullptr, workspace_bytes);
+  return (g_ring == 2 || (g_ring == 1 && prefer_ring(A_DENSE, p))) ? 1 : 0;
+}
+
 extern "C" size_t pm_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int act) {
   int ktps;
   const int s = choose_splits(M, N, K, act, &ktps);

@@ -20,6 +20,18 @@ import os
 import numpy as np
 import torch
 
+_CAPTURE_STREAMS = {}
+
+
+def _capture_streams(dev):
+    """ONE long-lived (capture, second-branch) stream pair per device.  HipOps keeps a split-K workspace (256 MB) and
+    the fp8 pack buffers per raw stream handle: a fresh pair per captured graph - a re-capture happens whenever the
+    condition tensors move, e.g. every round of generate_multiround - pinned another set each time, and a capture
+    on torch's own default capture stream never saw the workspace warmed up for it."""
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    if key not in _CAPTURE_STREAMS:
+        _CAPTURE_STREAMS[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+    return _CAPTURE_STREAMS[key]
 
 
 def make_ddim_timesteps(method, num_ddim, num_ddpm):
@@ -51,8 +63,9 @@ class _ForwardGraph:
         self.t = t.clone()
         dev = x.device
         two = uc is not None and os.environ.get("PANDORA_CFG_STREAMS", "1") != "0"
-        side = torch.cuda.Stream(device=dev)
-        other = torch.cuda.Stream(device=dev) if two else None
+        side, other = _capture_streams(dev)
+        if not two:
+            other = None
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):  # warm-up outside capture: packs weights, sizes the allocator
             model.apply_model(self.x, self.t, c, fs=fs, **kwargs)
@@ -64,7 +77,7 @@ class _ForwardGraph:
             torch.cuda.current_stream(dev).wait_stream(other)
             torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=side):  # the stream whose workspace the warm-up above sized
             main = torch.cuda.current_stream(dev)
             if two:
                 other.wait_stream(main)  # fork
@@ -96,7 +109,7 @@ class _SegmentedForward:
     def __init__(self, model, x, t, c, fs, kwargs, fp):
         self.x, self.t = x.clone(), t.clone()
         dev = x.device
-        self._side = torch.cuda.Stream(device=dev)
+        self._side = _capture_streams(dev)[0]
         self._side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self._side):  # warm-up on the capture stream: weights packed, split-K scratch sized
             model.apply_model(self.x, self.t, c, fs=fs, **kwargs)
@@ -150,6 +163,35 @@ class _SegmentedForward:
         return self.out
 
 
+def _segments_supported(fp, dev):
+    """Collective go / no-go for the segmented replay (a per-rank fallback leaves the ranks at different
+    points of the exchange sequence).  Every rank of the frame group runs the same tiny rehearsal - capture, RCCL call
+    next to the capture, capture - and the minimum of the outcomes decides for ALL of them."""
+    import torch.distributed as dist
+    ok = 1
+    try:
+        side = _capture_streams(dev)[0]
+        side.wait_stream(torch.cuda.current_stream(dev))
+        pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.stream(side):
+            buf = torch.zeros(64, device=dev)
+        for k in range(2):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, stream=side, capture_error_mode="thread_local"):
+                buf.add_(1.0)
+            g.replay()
+            if k == 0:
+                with torch.cuda.stream(side):
+                    dist.all_reduce(buf, group=fp.group)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+    except Exception:  # noqa: BLE001 - any failure means "eager", decided below for every rank at once
+        ok = 0
+    flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=fp.group)
+    return bool(flag.item())
+
+
 class DDIMSampler:
     def __init__(self, model, schedule="linear", use_graph=None, cfg_parallel=None, ops=None, **kwargs):
         """`ops`: the op table for the fused update kernel; default = the one bound to model's U-Net.  Pass it
@@ -164,7 +206,8 @@ class DDIMSampler:
         # HIP-graph replay of the forwards (single-GPU HipOps only; PANDORA_HIPGRAPH=0 disables)
         self.use_graph = (os.environ.get("PANDORA_HIPGRAPH", "1") != "0") if use_graph is None else use_graph
         self._graphs = {}
-        self._seg_failed = False  # a segmented capture raised once: eager from then on
+        self._seg_failed = False  # the frame group decided against segmented replay (or, at one rank, a capture raised)
+        self._seg_probed = False
         self._gen = None  # multi-rank noise generator (see _draw)
 
     def _fp(self):
@@ -186,8 +229,10 @@ class DDIMSampler:
             seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
             t = seed.to(device) if dist.get_backend() == "nccl" else seed
             dist.broadcast(t, src=0)
-            self._gen = torch.Generator(device="cpu").manual_seed(int(t.item()))
-        return torch.randn(shape, generator=self._gen).to(device)
+            # a generator ON the device: identical GPUs give identical Philox streams, and no host randn + blocking
+            # H2D copy sits in the step loop
+            self._gen = torch.Generator(device=device).manual_seed(int(t.item()))
+        return torch.randn(shape, generator=self._gen, device=device)
 
     def _ops(self):
         ops = self._ops_override or getattr(self.model, "ops", None)
@@ -280,6 +325,8 @@ class DDIMSampler:
         pair = self.cfg_parallel is not None and use_cfg  # this rank runs ONE branch, then one exchange
 
         def replay(cc, uu):
+            if hasattr(unet, "packed") and getattr(unet, "ops", None) is not None:
+                unet.packed()  # re-packs (and moves the pack epoch in the key below) after an in-place weight edit
             tensors = [v for d in (cc, uu or {}) for lst in d.values() for v in lst] + ([fs] if torch.is_tensor(fs) else [])
             # (a weight reload / .to() re-packs the kernel-side weights: the captured graph holds raw pointers to the
             # old ones, so the U-Net's pack epoch is part of the key)
@@ -298,6 +345,15 @@ class DDIMSampler:
                        and fp_u is not None and fp_u.backend == "nccl" and not self._seg_failed
                        and os.environ.get("PANDORA_SEGMENT_GRAPHS", "1") != "0")
 
+        if segmentable and not self._seg_probed and fp_u.world > 1:
+            self._seg_probed = True
+            if not _segments_supported(fp_u, x.device):
+                import warnings
+                warnings.warn("segmented graph replay is not available on this RCCL build (rehearsal failed on at "
+                              "least one rank of the frame group): every rank issues the forward eagerly")
+                self._seg_failed = True
+                segmentable = False
+
         def forward_sharded(cc, slot):
             if segmentable:
                 tensors = [v for lst in cc.values() for v in lst] + ([fs] if torch.is_tensor(fs) else [])
@@ -310,6 +366,13 @@ class DDIMSampler:
                     try:
                         g = self._graphs[key] = _SegmentedForward(self.model, x, t, cc, fs, kwargs, fp_u)
                     except Exception as exc:  # e.g. an RCCL build that refuses calls next to a capture
+                        if fp_u.world > 1:
+                            # peers are somewhere inside the recorded exchange sequence: restarting this rank's forward
+                            # eagerly would pair its first exchange with their k-th (hang or silently wrong data)
+                            raise RuntimeError("segmented graph capture of the frame-sharded forward failed on this rank "
+                                               "after the frame group's rehearsal succeeded; aborting instead of "
+                                               "falling back locally (PANDORA_SEGMENT_GRAPHS=0 selects the eager "
+                                               "forward on every rank)") from exc
                         import warnings
                         warnings.warn(f"segmented graph capture of the frame-sharded forward failed ({exc!r}): eager")
                         self._seg_failed = True
@@ -439,6 +502,8 @@ class DDIMSampler:
                 intermediates["pred_x0"].append(pred_x0)
         if fp is not None:
             img = fp.gather_frames(img)
+            if getattr(fp, "mailbox", None) is not None:
+                fp.mailbox.check()  # (once per clip: a timed-out peer exchange invalidates the latent)
         if precision is not None and isinstance(precision, torch.dtype):
             img = img.to(precision)
         return img, intermediates

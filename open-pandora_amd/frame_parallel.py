@@ -20,10 +20,100 @@ object provides to UNetModel:
                  gather_kv is kept as the all-gather form).
 
 The single-GPU result of the same kernels is the oracle for this mode (the reference has no
-counterpart): tests/test_frame_parallel_cpu.py checks equality with world_size 2 on gloo.
+counterpart): tests/test_frame_parallel_cpu.py checks equality with world sizes 2, 4 and 8 on gloo.
+
+On the GPU (`ops` = HipOps) the two latency-class exchanges - exchange_stats_halo and reduce_stats, 105 of the 139 per
+forward - go through `PeerMailbox` instead of torch.distributed: one kernel launch each, direct peer writes into
+hipIpc-mapped mailboxes (csrc/peer.hip), so only the 34 bulk all-to-alls remain RCCL calls and everything between
+two of them replays as one HIP graph (tests/test_peer_gpu.py: 2 and 4 processes sharing one MI355X).
 """
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
+
+from . import capi
+
+
+class PeerMailbox:
+    """hipIpc-mapped mailboxes of one frame group (csrc/peer.hip, include/pandora_mi355x.h `pm_peer_*`): the 256-byte
+    GroupNorm partial sums to every rank and the boundary frames to the two neighbours travel as direct peer writes
+    of ONE kernel launch per exchange - no RCCL call, no host wait, capturable inside a HIP graph.  Created lazily
+    (and collectively) at the first exchange, sized by the largest halo frame seen; a larger one re-creates it."""
+
+    NSTAT_MAX = 256
+
+    def __init__(self, ops, group, rank, world):
+        self.ops, self.lib, self.group, self.rank, self.world = ops, ops.lib, group, rank, world
+        self.base = None
+        self.halo_max = 0
+        self.fine_grained = None
+        self.exchanges = 0
+        self.timeout_s = float(os.environ.get("PANDORA_PEER_TIMEOUT_S", "5"))
+
+    def _create(self, halo_bytes):
+        self.close()
+        torch.cuda.synchronize(self.ops.device)
+        self.halo_max = int(halo_bytes)
+        nbytes = self.lib.pm_peer_mailbox_bytes(self.world, self.NSTAT_MAX, self.halo_max)
+        base, fg = ctypes.c_void_p(), ctypes.c_int()
+        handle = ctypes.create_string_buffer(64)
+        capi.check(self.lib.pm_peer_create(nbytes, ctypes.byref(base), handle, ctypes.byref(fg)), "pm_peer_create")
+        self.base, self.fine_grained = base, bool(fg.value)
+        handles = [None] * self.world
+        dist.all_gather_object(handles, bytes(handle.raw), group=self.group)
+        self.peers = (ctypes.c_void_p * self.world)()
+        for r in range(self.world):
+            if r != self.rank:
+                p = ctypes.c_void_p()
+                capi.check(self.lib.pm_peer_open(handles[r], ctypes.byref(p)), f"pm_peer_open (rank {r})")
+                self.peers[r] = p
+        dist.barrier(group=self.group)  # every mailbox is mapped everywhere before the first write
+
+    def close(self):
+        if self.base is None:
+            return
+        torch.cuda.synchronize(self.ops.device)
+        dist.barrier(group=self.group)  # nobody still writes into a mailbox that is about to go
+        for r in range(self.world):
+            if r != self.rank and self.peers[r]:
+                self.lib.pm_peer_close(self.peers[r])
+        self.lib.pm_peer_destroy(self.base)
+        self.base = None
+
+    def check(self):
+        """Raise if any exchange since creation timed out (synchronous: once per clip, never per exchange)."""
+        if self.base is None:
+            return
+        epoch, err = ctypes.c_int(), ctypes.c_int()
+        capi.check(self.lib.pm_peer_status(self.base, ctypes.byref(epoch), ctypes.byref(err)), "pm_peer_status")
+        if err.value:
+            raise capi.PandoraKernelError(f"peer mailbox exchange timed out on rank {self.rank} (a peer never arrived "
+                                          f"within {self.timeout_s} s): the frame-sharded result is invalid")
+        return epoch.value
+
+    def exchange(self, stats, first=None, last=None):
+        """stats f32 [n] -> totals (rank-order sum); first / last [P, C] frames -> (frame before my first, after my last)."""
+        halo = 0 if first is None else first.numel() * first.element_size()
+        if self.base is None or halo > self.halo_max:
+            if torch.cuda.is_current_stream_capturing():
+                raise capi.PandoraKernelError("peer mailbox must be created before graph capture (warm-up forward)")
+            self._create(max(halo, self.halo_max))
+        assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.numel() <= self.NSTAT_MAX
+        tot = torch.empty_like(stats)
+        lo = hi = None
+        if first is not None:
+            assert first.is_contiguous() and last.is_contiguous() and first.shape == last.shape
+            lo = torch.empty_like(first) if self.rank > 0 else None
+            hi = torch.empty_like(first) if self.rank < self.world - 1 else None
+        ptr = lambda t: None if t is None else t.data_ptr()
+        rc = self.lib.pm_peer_exchange(self.base, self.peers, self.rank, self.world, ptr(stats), stats.numel(),
+                                       ptr(first), ptr(last), halo, ptr(tot), ptr(lo), ptr(hi), self.NSTAT_MAX,
+                                       self.halo_max, self.timeout_s, self.ops._stream())
+        capi.check(rc, "pm_peer_exchange")
+        self.exchanges += 1
+        return tot, lo, hi
 
 
 def _host_staged_sync(t, group=None):
@@ -34,9 +124,13 @@ def _host_staged_sync(t, group=None):
 
 
 class FrameParallel:
-    def __init__(self, total_frames, ops=None, group=None):
+    def __init__(self, total_frames, ops=None, group=None, kv_gather=False):
+        """`kv_gather`: the north-star's literal form of the temporal attention - every rank keeps its frames and
+        all-gathers K|V over the frame axis (`gather_kv`) - instead of the frames <-> pixels re-shard."""
         assert dist.is_initialized(), "init_process_group first (one process per GPU)"
         self.group = group
+        self.kv_gather = kv_gather
+        self.mailbox = None  # set below: PeerMailbox when `ops` drives a GPU (PANDORA_PEER_MAILBOX=0: the P2P form)
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         # P2POp peers are global ranks: map group-local neighbours to global ids
@@ -51,6 +145,10 @@ class FrameParallel:
         # closure over buffers that were allocated BEFORE the call (so a replay re-issues the same RCCL calls on
         # the same addresses, between the HIP graphs that hold the kernels around them)
         self.recorder = None
+        if self.world > 1 and ops is not None and hasattr(ops, "lib") and hasattr(ops.lib, "pm_peer_exchange") \
+                and os.environ.get("PANDORA_PEER_MAILBOX", "1") != "0":
+            self.mailbox = PeerMailbox(ops, group, self.rank, self.world)
+            self.calls["mailbox"] = 0
 
     def _comm(self, fn):
         if self.recorder is None:
@@ -86,6 +184,10 @@ class FrameParallel:
     def reduce_stats(self, partial, local_count):
         """partial f32 [NI, groups, 2] local {sum, sumsq} -> (all-rank totals, total element count)."""
         self.calls["reduce_stats"] += 1
+        if self.mailbox is not None:
+            self.calls["mailbox"] += 1
+            tot, _, _ = self.mailbox.exchange(partial.contiguous().view(-1))
+            return tot.view_as(partial), float(local_count) * self.world
         tot = partial.contiguous().clone()
         _host_staged_sync(tot, self.group)
         self._comm(lambda: dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group))
@@ -122,6 +224,10 @@ class FrameParallel:
         part = partial.contiguous()
         first = x[:P].contiguous()
         last = x[(self.local_frames - 1) * P:].contiguous()
+        if self.mailbox is not None:  # one kernel launch: peer writes + arrival counters, same rank-order totals
+            self.calls["mailbox"] += 1
+            tot, lo, hi = self.mailbox.exchange(part.view(-1), first, last)
+            return tot.view_as(part), float(local_count) * self.world, lo, hi
         _host_staged_sync(x, self.group)
         lo = torch.empty_like(first) if self.rank > 0 else None
         hi = torch.empty_like(first) if self.rank < self.world - 1 else None
@@ -207,7 +313,7 @@ class CFGParallel:
         return (e_mine, e_other) if self.branch == 0 else (e_other, e_mine)
 
 
-def make_hybrid(total_frames, use_cfg=True):
+def make_hybrid(total_frames, use_cfg=True, kv_gather=False, ops=None):
     """Decompose the world for one clip: with CFG on and an even world size, ranks [0, N/2) take the
     conditional branch and [N/2, N) the unconditional one (CFGParallel pairs r <-> r + N/2); inside a
     branch the N/2 ranks shard the frames (FrameParallel on a sub-group).  Returns (fp, cfgp); either
@@ -215,11 +321,11 @@ def make_hybrid(total_frames, use_cfg=True):
     world, rank = dist.get_world_size(), dist.get_rank()
     if world == 1:
         return None, None
-    if not use_cfg or world % 2:
-        return FrameParallel(total_frames), None
+    if not use_cfg or world % 2:  # (use_cfg=False + kv_gather=True at world 8 = the north-star's split: 2 frames per GPU)
+        return FrameParallel(total_frames, ops=ops, kv_gather=kv_gather), None
     half = world // 2
     groups = [dist.new_group(list(range(b * half, (b + 1) * half))) for b in (0, 1)]
     branch = rank // half
     cfgp = CFGParallel(partner=(rank + half) % world, branch=branch)
-    fp = FrameParallel(total_frames, group=groups[branch]) if half > 1 else None
+    fp = FrameParallel(total_frames, ops=ops, group=groups[branch], kv_gather=kv_gather) if half > 1 else None
     return fp, cfgp

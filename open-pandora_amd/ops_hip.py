@@ -139,7 +139,14 @@ class HipOps:
         col_scale f32 [N] (instead of a bias): column n is multiplied by col_scale[n] in f32 before the store.
         split_a (f32 `a`, stream output): two passes, a = hi + lo in 16 bit each (PM_FLAG_A_LO)."""
         wrap = 0
-        if a.dtype == torch.float32 and self.presplit and a.shape[1] % 64 == 0:
+        if a.shape[1] % 64:
+            # pm_gemm walks whole 64-wide K-tiles (every Linear of the U-Net has K % 64 == 0); narrower models (the
+            # reduced-width first-stage encoder's 1x1 shortcut) get both operands zero-padded along K, ONCE, before
+            # any of the passes below: same product (ADVICE r02: the low pass of split_a used to see the unpadded K)
+            pad = 64 - a.shape[1] % 64
+            a = torch.nn.functional.pad(a, (0, pad))
+            w = torch.nn.functional.pad(w, (0, pad)).contiguous()
+        if a.dtype == torch.float32 and self.presplit:
             # the f32 stream as an operand of the DMA-staged 16-bit kernels: one pass of pm_split16 in front
             # (split_a: [hi | lo] against W walked twice - the two-pass PM_FLAG_A_LO product in one launch)
             both = split_a and stream and act == "none"
@@ -151,13 +158,6 @@ class HipOps:
         M, K = a.shape
         N = w.shape[0]
         assert w.shape[1] * (2 if wrap else 1) == K and w.is_contiguous() and w.dtype == self.dtype
-        if K % 64 and not wrap:
-            # pm_gemm walks whole 64-wide K-tiles (every Linear of the U-Net has K % 64 == 0); narrower models (the
-            # reduced-width first-stage encoder's 1x1 shortcut) get both operands zero-padded along K: same product
-            pad = 64 - K % 64
-            a = torch.nn.functional.pad(a, (0, pad))
-            w = torch.nn.functional.pad(w, (0, pad))
-            K += pad
         n_out = N // 2 if act == "geglu" else N
         flags, out = self._gemm_io(a, residual, out, M, n_out, stream)
         flags |= wrap
@@ -196,8 +196,9 @@ class HipOps:
     def conv3x3(self, x, wp, bias, F, H, W, stride=1, upsample=False, residual=None, out=None, stream=False,
                 pad_lo=1, stats=None):
         """x [F*H*W, Cin] -> [F*Ho*Wo, Cout]; wp packed [Cout, 9*Cin]."""
-        if x.dtype == torch.float32 and self.presplit:
+        if x.dtype == torch.float32 and self.presplit and x.shape[1] % 8 == 0:
             x = self.split16(x)  # the f32 stream (Downsample / Upsample): rounded once here, then the DMA loaders
+            # (pm_split16 moves 8-element chunks: other widths keep the register-staged f32 loader)
         cin = x.shape[1]
         cout = wp.shape[0]
         assert x.shape[0] == F * H * W and wp.shape[1] == 9 * cin and wp.is_contiguous()
@@ -216,7 +217,7 @@ class HipOps:
     def conv_t3(self, x, wp, bias, F, P, residual=None, halo_lo=None, halo_hi=None, out=None, stream=False,
                 stats=None):
         """3-tap conv over frames: x [F*P, Cin] -> [F*P, Cout]; wp packed [Cout, 3*Cin]."""
-        if x.dtype == torch.float32 and self.presplit and halo_lo is None and halo_hi is None:
+        if x.dtype == torch.float32 and self.presplit and halo_lo is None and halo_hi is None and x.shape[1] % 8 == 0:
             x = self.split16(x)
         cin = x.shape[1]
         cout = wp.shape[0]

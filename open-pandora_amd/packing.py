@@ -40,7 +40,7 @@ class PackedWeights:
         self.register_load_state_dict_post_hook(lambda module, _incompatible: module.invalidate_packed())
 
     def invalidate_packed(self):
-        self._packed, self._packed_fp = None, None
+        self._packed, self._packed_fp, self._fp_sample = None, None, None
         self._pack_epoch += 1
 
     def _apply(self, fn, *args, **kwargs):  # .to() / .half() / .float() / .cuda() of this module or a parent
@@ -49,16 +49,29 @@ class PackedWeights:
 
     def _fingerprint(self):
         """(version counter, address) of a fixed sample of the parameters: an in-place edit bumps the version, a
-        re-assignment changes the address.  ~40 tensors: microseconds per forward."""
-        ps = list(self.parameters())
-        step = max(1, len(ps) // 40)
-        return (len(ps),) + tuple((p._version, p.data_ptr()) for p in ps[::step])
+        re-assignment changes the address.  The sample (~40 tensors) is listed once per pack: walking all ~1500
+        parameters per forward cost about a millisecond of host time; a re-assigned parameter object
+        is caught by the address of the slot it is read back from."""
+        sample = getattr(self, "_fp_sample", None)
+        if sample is None:
+            named = list(self.named_parameters())
+            step = max(1, len(named) // 40)
+            mods = dict(self.named_modules())
+            sample = self._fp_sample = (len(named), [(mods[n.rpartition(".")[0]], n.rpartition(".")[2]) for n, _ in named[::step]])
+        out = []
+        for mod, leaf in sample[1]:
+            p = getattr(mod, leaf)
+            out.append((p._version, p.data_ptr()))
+        return (sample[0],) + tuple(out)
 
     def packed(self):
-        """the current packed weight set, rebuilt (prepare()) if the parameters changed since it was made"""
+        """the current packed weight set, rebuilt (prepare()) if the parameters changed since it was made.  Holders of
+        derived state (a captured HIP graph) call this before every reuse: a replay does not walk forward(), so an
+        in-place weight edit would otherwise go unnoticed by the graph."""
         if self._packed is None or self._packed_fp != self._fingerprint():
             if self._packed is not None:
                 self.invalidate_packed()
+            self._fp_sample = None
             self.prepare()
             self._packed_fp = self._fingerprint()
         return self._packed

@@ -484,7 +484,7 @@ class UNetModel(packing.PackedWeights, nn.Module):
         ops, e = c.ops, c.w[self._names[mod]]
         F, P = c.F, c.H * c.W
         h = self._gn(c, x, e["norm"], 1e-6, False, not temporal)
-        sharded = temporal and c.fp is not None and P % c.fp.world == 0
+        sharded = temporal and c.fp is not None and P % c.fp.world == 0 and not c.fp.kv_gather
         gather = temporal and c.fp is not None and not sharded  # (pixel count not divisible: tiny maps)
         if sharded:  # frames <-> pixels: the temporal block needs all T frames of a pixel, nothing else
             h = c.fp.frames_to_pixels(h, P)

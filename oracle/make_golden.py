@@ -5,6 +5,7 @@ Run in the build container only:   python -m oracle.make_golden [--full] [--traj
   default : schedule tables, module-level and reduced-width U-Net / DDIM fixtures (seconds)
   --full  : one full-width (1.44 B parameter) U-Net forward at 40x64, cond + uncond (minutes)
   --traj  : full-width 10-step eta=0 CFG trajectory at 40x64 = BASELINE config 1 (~20-30 min)
+  --frames / --frames-full "10:0,50:1" : end-to-end FRAMES (sampler -> decode_first_stage), reduced / full width
 Fixtures hold inputs' seeds and expected outputs only (data, no reference source).
 """
 import argparse
@@ -308,6 +309,78 @@ def gen_full_72x128(traj_steps=0):
         save(f"ddim_full_72x128_s{traj_steps}.npz", **out)
 
 
+def _reference_first_stage(ch=128):
+    """The real AutoencoderKL (lvdm/models/autoencoder.py) on seeded weights, as `first_stage_model`."""
+    rh._install_shims()
+    from lvdm.models.autoencoder import AutoencoderKL
+    from open_pandora_amd.autoencoder import DDCONFIG
+    ae = AutoencoderKL(ddconfig=dict(DDCONFIG, ch=ch), lossconfig=rh.AttrDict(target="torch.nn.Identity"),
+                       embed_dim=4).eval()
+    ae.load_state_dict(synth.synth_state_dict(ae, seed=WEIGHT_SEED))
+    return ae
+
+
+def _sample_and_decode(m, ins, cond, uc, h, w, S, eta, shared_noise):
+    """The real DDIMSampler.sample (ddim.py:66) followed by the real LatentDiffusion.decode_first_stage
+    (ddpm3d.py:630-655, per-frame AE): latents -> frames."""
+    import lvdm.models.samplers.ddim as refddim
+    if shared_noise:  # eta > 0: every draw of noise_like comes from the seeded recipe (gr.noises), as in gen_ddim_small
+        noises = iter(gr.noises(ins["x_T"].shape, S))
+        refddim.noise_like = lambda shape, device, repeat=False: next(noises)
+    smp = rh.reference_sampler(m)
+    z, _ = smp.sample(S=S, batch_size=1, shape=(4, 16, h, w), conditioning=cond, verbose=False,
+                      unconditional_guidance_scale=4.0, unconditional_conditioning=uc, eta=eta,
+                      fs=torch.tensor([15]), timestep_spacing="uniform_trailing", x_T=ins["x_T"])
+    with torch.no_grad():
+        frames = m.decode_first_stage(z)
+    return z, frames
+
+
+def gen_frames_small():
+    """End-to-end FRAMES at reduced width (the north-star's tolerance is on frames): sampler -> decode_first_stage,
+    all-reference, stored in full (1, 3, 16, 64, 64)."""
+    out = {}
+    m = rh.reference_diffusion(dict(model_channels=64))
+    m.model.diffusion_model.load_state_dict(synth.synth_state_dict(m.model.diffusion_model, seed=WEIGHT_SEED))
+    m.first_stage_model = _reference_first_stage(ch=32)
+    ins, cond, uc = _small_setup()
+    for S, eta in gr.FRAMES_SMALL_CASES:
+        z, frames = _sample_and_decode(m, ins, cond, uc, 8, 8, S, eta, shared_noise=eta > 0)
+        out[f"S{S}_eta{eta:g}/latent"] = z.numpy()
+        out[f"S{S}_eta{eta:g}/frames"] = frames.numpy()
+    save("frames_small.npz", **out)
+
+
+def gen_frames_full(cases):
+    """Full width (1.44 B U-Net, full AutoencoderKL) at 16x40x64 -> 320x512 frames through the REAL reference:
+    (10, 0.0) = BASELINE config 1 (eta 0) and (50, 1.0) = the production schedule with the recipe's shared noise.
+    Hours of CPU: run in the background (`nice`), digests only."""
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count() or 8)))
+    t0 = time.time()
+    m = rh.reference_diffusion()
+    unet = m.model.diffusion_model
+    unet.load_state_dict(synth.synth_state_dict(unet, seed=WEIGHT_SEED))
+    m.first_stage_model = _reference_first_stage()
+    print(f"full model + first stage ready in {time.time() - t0:.0f}s", flush=True)
+    h, w = 40, 64
+    ins, cond, uc = _small_setup(320, h, w)
+    for S, eta in cases:
+        t0 = time.time()
+        z, frames = _sample_and_decode(m, ins, cond, uc, h, w, S, eta, shared_noise=eta > 0)
+        dt = time.time() - t0
+        print(f"S={S} eta={eta}: {dt:.0f}s latent std {z.std():.4f} frames std {frames.std():.4f}", flush=True)
+        out = {"source": np.array("the real reference: DDIMSampler.sample + LatentDiffusion.decode_first_stage")}
+        for k, v in digest(z, n=8192).items():
+            out[f"latent/{k}"] = v
+        for k, v in digest(frames, n=16384).items():
+            out[f"frames/{k}"] = v
+        out["frames/per_frame_mean"] = frames[0].double().mean(dim=(0, 2, 3)).numpy()
+        out["frames/per_frame_std"] = frames[0].double().std(dim=(0, 2, 3)).numpy()
+        out["wall_seconds"] = np.float64(dt)
+        out["threads"] = np.int64(torch.get_num_threads())
+        save(f"frames_full_40x64_s{S}_eta{eta:g}.npz", **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full-72x128", action="store_true")
@@ -319,7 +392,16 @@ if __name__ == "__main__":
     ap.add_argument("--ae", action="store_true")
     ap.add_argument("--rescale", action="store_true")
     ap.add_argument("--resampler", action="store_true")
+    ap.add_argument("--frames", action="store_true", help="reduced-width sampler -> decode_first_stage frames (seconds)")
+    ap.add_argument("--frames-full", default="", help='full-width cases "S:eta,S:eta", e.g. "10:0,50:1" (hours of CPU)')
     a = ap.parse_args()
+    if a.frames or a.frames_full:
+        assert rh.available()
+        if a.frames:
+            gen_frames_small()
+        if a.frames_full:
+            gen_frames_full([(int(c.split(":")[0]), float(c.split(":")[1])) for c in a.frames_full.split(",")])
+        sys.exit(0)
     if a.ctx:
         assert rh.available()
         gen_unet_ctx()

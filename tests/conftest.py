@@ -10,6 +10,31 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes of CPU (full-width oracle / live-reference runs); "
+                                       'casual runs: -m "not gpu and not slow"')
+
+
+# Measured margins, not just "<= threshold": every `[parity]` / `[budget]` / `[scaling]` line a test prints is collected from
+# the captured output and repeated in the terminal summary, so the tail of a `pytest -q` log (the driver's GPUTEST record)
+# carries the numbers themselves.
+_MEASURED = []
+
+
+def pytest_runtest_logreport(report):
+    if report.when != "call":
+        return
+    for line in (report.capstdout or "").splitlines():
+        line = line.strip()
+        if line.startswith(("[parity]", "[budget]", "[scaling]")):
+            _MEASURED.append(line)
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not _MEASURED:
+        return
+    terminalreporter.section("measured margins ([parity] / [budget] lines of the tests that ran)")
+    for line in _MEASURED:
+        terminalreporter.write_line(line)
 
 
 @pytest.fixture(scope="session")

@@ -33,8 +33,12 @@ def test_product_refuses_to_run_without_ops():
     m = UNetModel(in_channels=8, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=[1],
                   channel_mult=[1], num_head_channels=64, context_dim=1024, use_linear=True,
                   use_relative_position=False, temporal_length=16)
-    with pytest.raises(RuntimeError):
-        m(torch.zeros(1, 8, 16, 8, 8), torch.tensor([1]), context=torch.zeros(1, 333, 1024))
+    # inference (eval / no_grad, as WorldModel.generate runs it) without an op table: loud, no eager fallback.  (In
+    # training mode with autograd on the module takes the differentiable path instead: tests/test_boundary_cpu.py.)
+    with pytest.raises(RuntimeError, match="bind"):
+        m.eval()(torch.zeros(1, 8, 16, 8, 8), torch.tensor([1]), context=torch.zeros(1, 333, 1024))
+    with torch.no_grad(), pytest.raises(RuntimeError, match="bind"):
+        m.train()(torch.zeros(1, 8, 16, 8, 8), torch.tensor([1]), context=torch.zeros(1, 333, 1024))
 
 
 def test_hip_ops_fail_loudly_on_cpu():

@@ -77,6 +77,22 @@ def test_gemm_split_f32_operand(hip_ops_factory, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("presplit", [True, False])
+def test_f32_operand_shape_edges(hip_ops_factory, monkeypatch, dtype, presplit):
+    """K % 64 != 0 with an f32 A operand (split_a's low pass used to see the unpadded K -> PM_E_SHAPE): both
+    operands are zero-padded once, in front of every pass, with and without the pm_split16 pre-pass."""
+    ops = hip_ops_factory(dtype)
+    monkeypatch.setattr(ops, "presplit", presplit)
+    M, N, K = 300, 64, 96
+    a = rnd(M, K, dtype=torch.float32, scale=2.0, seed=1)
+    w, bias = rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=2), rnd(N, dtype=torch.float32, seed=3)
+    want = a @ w.float().t() + bias
+    got = ops.gemm(a.cuda(), w.cuda(), bias.cuda(), stream=True, split_a=True)
+    assert rel_err(got, want) <= (2e-5 if dtype == torch.float16 else 1e-4)
+    assert rel_err(ops.gemm(a.cuda(), w.cuda(), bias.cuda(), stream=True), want) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(300, 320, 640), (2560, 1280, 2560), (4099, 320, 960)])
 def test_split16_and_wrapped_weights(hip_ops_factory, monkeypatch, dtype, M, N, K):
     """pm_split16 is bit-exact ([hi | lo] = the roundings PM_FLAG_A_F32 / PM_FLAG_A_LO apply while staging), and

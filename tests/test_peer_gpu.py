@@ -1,0 +1,193 @@
+"""GPU, 2 and 4 processes sharing the one MI355X: the peer-mailbox exchange (csrc/peer.hip, frame_parallel.PeerMailbox)
+- direct peer writes into hipIpc-mapped mailboxes, one kernel launch per exchange, no RCCL, no host wait.
+
+* unit: partial sums come back as the rank-order total (bit for bit), halo frames are the neighbours' frames (bit for
+  bit), over many exchanges of changing sizes (the two-slot / epoch protocol), eagerly AND replayed from a captured
+  HIP graph (the launch carries no per-call host state: the epoch lives in the mailbox);
+* integration: a frame-sharded DDIM run of the reduced U-Net on HipOps with the mailbox equals the same run with the
+  torch.distributed point-to-point form bit for bit (same partial sums, same rank-order totals), the single-process
+  run to rounding, and leaves <= 35 torch.distributed calls per forward (the bulk all-to-alls / K|V gathers).
+
+Processes of one GPU cannot form an RCCL communicator (one rank per device), so the group backend here is gloo (host
+staged, as in the r02 rehearsals); the mailbox path itself never touches it after the handle exchange."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PANDORA_PEER_TIMEOUT_S="20")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _frame(rank, it, P, C, which):
+    g = torch.Generator().manual_seed(1000 * it + 10 * rank + which)
+    return torch.randn(P, C, generator=g)
+
+
+def _stats(rank, it, n):
+    g = torch.Generator().manual_seed(77777 + 1000 * it + rank)
+    return torch.randn(n, generator=g)
+
+
+def _unit_worker(rank, world, port, out):
+    _init(rank, world, port)
+    try:
+        from open_pandora_amd.frame_parallel import FrameParallel
+        from open_pandora_amd.ops_hip import HipOps
+        ops = HipOps(torch.float16, "cuda:0")
+        fp = FrameParallel(16, ops=ops)
+        mb = fp.mailbox
+        assert mb is not None
+        log = []
+        shapes = [(256, 96), (64, 320), (16, 640), (256, 96), (4, 1280), (64, 320)]  # the largest comes first, as in the U-Net
+        for it in range(40):
+            P, C = shapes[it % len(shapes)]
+            n = (64, 64, 128, 32)[it % 4]
+            st = _stats(rank, it, n).cuda()
+            if it % 5 == 4:  # statistics only (the TemporalTransformer GroupNorms)
+                tot, lo, hi = mb.exchange(st)
+            else:
+                tot, lo, hi = mb.exchange(st, _frame(rank, it, P, C, 0).cuda(), _frame(rank, it, P, C, 1).cuda())
+            want = _stats(0, it, n)
+            for r in range(1, world):
+                want = want + _stats(r, it, n)  # rank order, f32: the kernel's order
+            ok = torch.equal(tot.cpu(), want)
+            if it % 5 != 4:
+                ok = ok and (lo is None) == (rank == 0) and (hi is None) == (rank == world - 1)
+                if lo is not None:
+                    ok = ok and torch.equal(lo.cpu(), _frame(rank - 1, it, P, C, 1))  # the previous rank's LAST frame
+                if hi is not None:
+                    ok = ok and torch.equal(hi.cpu(), _frame(rank + 1, it, P, C, 0))  # the next rank's FIRST frame
+            log.append(bool(ok))
+        # ---- the same launches replayed from ONE captured HIP graph, inputs refreshed in static buffers ----
+        P, C, n = 64, 320, 64
+        s_in, f_in, l_in = torch.zeros(n, device="cuda"), torch.zeros(P, C, device="cuda"), torch.zeros(P, C, device="cuda")
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            t1, lo1, hi1 = mb.exchange(s_in, f_in, l_in)
+            t2, _, _ = mb.exchange(t1 * 0.5)  # a dependent, statistics-only exchange in the same graph
+            t3, lo3, hi3 = mb.exchange(s_in + 1.0, l_in, f_in)
+        glog = []
+        for it in range(100, 108):
+            s_in.copy_(_stats(rank, it, n)), f_in.copy_(_frame(rank, it, P, C, 0)), l_in.copy_(_frame(rank, it, P, C, 1))
+            g.replay()
+            torch.cuda.synchronize()
+            want = _stats(0, it, n)
+            for r in range(1, world):
+                want = want + _stats(r, it, n)
+            w2 = want * 0.5
+            for r in range(1, world):
+                w2 = w2 + want * 0.5
+            w3 = _stats(0, it, n) + 1.0
+            for r in range(1, world):
+                w3 = w3 + (_stats(r, it, n) + 1.0)
+            ok = torch.equal(t1.cpu(), want) and torch.equal(t2.cpu(), w2) and torch.equal(t3.cpu(), w3)
+            if rank > 0:
+                ok = ok and torch.equal(lo1.cpu(), _frame(rank - 1, it, P, C, 1)) and torch.equal(lo3.cpu(), _frame(rank - 1, it, P, C, 0))
+            if rank < world - 1:
+                ok = ok and torch.equal(hi1.cpu(), _frame(rank + 1, it, P, C, 0)) and torch.equal(hi3.cpu(), _frame(rank + 1, it, P, C, 1))
+            glog.append(bool(ok))
+        epoch = mb.check()
+        torch.save({"log": log, "glog": glog, "epoch": epoch, "fine_grained": mb.fine_grained}, f"{out}.{rank}")
+        mb.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_mailbox_exchange_unit(tmp_path, world):
+    out = str(tmp_path / "u.pt")
+    mp.spawn(_unit_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        got = torch.load(f"{out}.{r}")
+        assert all(got["log"]), (r, got["log"])
+        assert all(got["glog"]), (r, got["glog"])
+        assert got["epoch"] == 40 + 3 * 8  # every exchange closed its slot (the capture itself launches nothing)
+        print(f"\n[parity] peer mailbox world={world} rank {r}: 40 eager + 24 replayed exchanges bit-exact "
+              f"(fine-grained memory: {got['fine_grained']})")
+
+
+def _build(ops, fp):
+    from oracle import golden_recipe as gr
+    from open_pandora_amd import synth
+    from open_pandora_amd.ddpm import LatentVisualDiffusion
+    from open_pandora_amd.unet import UNetModel
+    from test_oracle_golden import RH_KW
+    m = UNetModel(**dict(RH_KW, model_channels=64)).eval()
+    m.load_state_dict(synth.synth_state_dict(m, seed=gr.WEIGHT_SEED))
+    m.bind(ops, fp)
+    return LatentVisualDiffusion(m)
+
+
+def _sample(pm, S=2, eta=1.0):
+    from oracle import golden_recipe as gr
+    from open_pandora_amd.ddim import DDIMSampler
+    ins, cond, uc = gr.sampler_inputs(8, 8)
+    dev = lambda d: {k: [v.cuda() for v in lst] for k, lst in d.items()}
+    ns = gr.noises(ins["x_T"].shape, S)
+    y, _ = DDIMSampler(pm).sample(S=S, batch_size=1, shape=(4, 16, 8, 8), conditioning=dev(cond), verbose=False,
+                                  unconditional_guidance_scale=4.0, unconditional_conditioning=dev(uc), eta=eta,
+                                  fs=torch.tensor([15]).cuda(), timestep_spacing="uniform_trailing", x_T=ins["x_T"].cuda(),
+                                  noise_fn=lambda i, shape: ns[i].cuda())
+    return y.float().cpu()
+
+
+def _unet_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    _init(rank, world, port)
+    try:
+        from open_pandora_amd.frame_parallel import FrameParallel
+        from open_pandora_amd.ops_hip import HipOps
+        ops = HipOps(torch.float16, "cuda:0")
+        res = {}
+        for tag, env in (("mailbox", "1"), ("p2p", "0")):
+            os.environ["PANDORA_PEER_MAILBOX"] = env
+            fp = FrameParallel(16, ops=ops)
+            assert (fp.mailbox is not None) == (env == "1")
+            res[tag] = _sample(_build(ops, fp))
+            res[tag + "_calls"] = dict(fp.calls)
+            if fp.mailbox is not None:
+                res["epoch"] = fp.mailbox.check()
+                fp.mailbox.close()
+        torch.save(res, f"{out}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 4])
+def test_frame_sharded_unet_through_the_mailbox(tmp_path, hip_ops_factory, world):
+    out = str(tmp_path / "y.pt")
+    mp.spawn(_unet_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    plain = _sample(_build(hip_ops_factory(torch.float16), None))
+    S = 2
+    for r in range(world):
+        got = torch.load(f"{out}.{r}")
+        assert torch.equal(got["mailbox"], got["p2p"]), r  # same partial sums, same rank-order totals: bit for bit
+        err = ((got["mailbox"] - plain).norm() / plain.norm()).item()
+        assert err < 3e-3, (r, err)  # the sharded sums round differently from the single-process ones (f16 operands)
+        c = got["mailbox_calls"]
+        per_fwd = 2 * S
+        assert c["mailbox"] == (88 + 17) * per_fwd and got["epoch"] == c["mailbox"]
+        rccl_like = (c["all_to_all"] + c.get("gather_kv", 0)) // per_fwd
+        assert rccl_like <= 35, c  # what is left for torch.distributed per forward (VERDICT r02 #3b)
+        print(f"\n[parity] frame shards world={world} rank {r}: mailbox == p2p bit for bit; vs single process {err:.2e}; "
+              f"{c['mailbox'] // per_fwd} mailbox launches + {rccl_like} collectives per forward")
