@@ -39,6 +39,11 @@ extern "C" {
 #define PM_F16 1
 #define PM_BF16 2
 #define PM_F32 3 /* only where an entry point says so (norm inputs, model outputs, the residual stream) */
+#define PM_OUT_HILO 0x100 /* OR-ed into the out_dtype of pm_groupnorm_apply / pm_layernorm (the parity configuration): row m
+                           * of y is [hi | lo] over 2C columns, hi = round16(v), lo = round16(v - hi) (ldy >= 2C).  A
+                           * GEMM / conv over the 2C channels with the weights repeated then sees the normalised
+                           * activation - the A operand whose 16-bit rounding is 57 % of the end-to-end error^2
+                           * (tests/test_error_budget_gpu.py) - at about twice the mantissa, for twice the MFMA work */
 
 /* GEMM-family flags.  The U-Net's residual stream (the tensor every block adds into) is kept in f32
  * so that 16-bit rounding happens once per branch operand instead of once per residual add. */
@@ -247,6 +252,13 @@ int pm_attention_fp8(const void* q, int64_t q_bs, int64_t q_rs, const void* k, c
 int pm_attention_generic(const void* q, int64_t q_bs, int64_t q_rs, const void* k, const void* v, int64_t k_bs,
                          int64_t k_rs, int64_t Nk, void* o, int64_t o_bs, int64_t o_rs, int64_t B, int64_t heads,
                          int64_t Nq, int64_t D, float scale, int dtype, void* stream);
+
+/* Diagnostics (tools/attn_bench.py, tools/attn_pmc.py; not used by the product path): overrides which kernel variant
+ * pm_attention / pm_attention_fp8 launch for single-segment calls - 0 = automatic (also the initial value, unless the
+ * environment variable PANDORA_ATTN_VARIANT is set: read once, on first use), 3 / 5 / 9 = older variants kept for A/B
+ * runs, 11 / 12 / 13 = ceiling probes of the production kernel whose OUTPUT IS NOT AN ATTENTION RESULT (no global
+ * traffic / no softmax / no LDS reads: csrc/attn.hip).  Process-wide, not thread-safe: measurement runs only. */
+void pm_debug_attn_variant(int variant);
 
 /* ------------------------------------------------------------------------------------------------
  * pm_attention_temporal: self-attention over the frame axis at every pixel (head dim 64).

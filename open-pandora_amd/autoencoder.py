@@ -230,6 +230,7 @@ class AutoencoderKL(packing.PackedWeights, nn.Module):
         C = x.shape[1]
         h = ops.groupnorm(x, *W["n"], 1e-6, F, False)
         q, k = ops.gemm(h, *W["q"]), ops.gemm(h, *W["k"])
+        h = h[:, :C]  # (parity op table: the norm output is [hi | lo]; V^T below takes it as the W operand: hi only)
         out = ops.empty(F * P, C)
         for f in range(F):  # one single-head (h*w x h*w) attention per frame
             sl = slice(f * P, (f + 1) * P)

@@ -10,6 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PANDORA_LIB", os.path.join(HERE, "libpandora_mi355x.so"))  # override: kernel experiments
 
 PM_F16, PM_BF16, PM_F32 = 1, 2, 3
+PM_OUT_HILO = 0x100
 PM_FLAG_A_F32, PM_FLAG_OUT_F32, PM_FLAG_RES_F32, PM_FLAG_BIAS_IS_SCALE, PM_FLAG_A_LO, PM_FLAG_W_WRAP = 1, 2, 4, 8, 16, 32
 PM_ACT_NONE, PM_ACT_SILU, PM_ACT_GEGLU, PM_ACT_GELU = 0, 1, 2, 3
 ACT_CODES = {"none": PM_ACT_NONE, None: PM_ACT_NONE, "silu": PM_ACT_SILU, "geglu": PM_ACT_GEGLU, "gelu": PM_ACT_GELU}
@@ -53,6 +54,7 @@ SIGNATURES = {
                                  c_void_p]),
     "pm_attention_generic": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p,
                                      c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int, c_void_p]),
+    "pm_debug_attn_variant": (None, [c_int]),
     "pm_attention_temporal": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                       c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int,
                                       c_void_p]),

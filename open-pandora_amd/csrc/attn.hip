@@ -300,7 +300,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 constexpr float STALE_THR = 6.0f;
 constexpr float STALE_SUM = 1024.0f;
 
-template <typename T, int QB, bool PIPE, bool POST, int RING>
+//
+// PROBE > 0 (diagnosis builds of the production configuration, reached through pm_debug_attn_variant 11 / 12 / 13;
+// their OUTPUT IS NOT AN ATTENTION RESULT): the same per-tile instruction stream with parts taken away, to measure what
+// this chip sustains for the mix at the clock it holds (profiles/r03/attention_ceiling.txt):
+//   1  no global traffic in the steady state: the first two K/V tiles stay in LDS and are re-read for every tile
+//      (same 16 MFMAs, same 2048-score softmax stream, same LDS fragment reads, same barriers);
+//   2  as 1 without the softmax's vector instructions (P = the low halves of S', no max / exp / sum / convert);
+//   3  as 2 without the LDS fragment reads (K and V fragments stay in registers): the bare MFMA stream.
+template <typename T, int QB, bool PIPE, bool POST, int RING, int PROBE = 0>
 __global__ __launch_bounds__(256, (QB == 1 && RING == 2) ? 3 : 2) void attn_self_kernel(const AttnParams p) {
   constexpr bool NOBAR = false;
   __shared__ __attribute__((aligned(16))) char smem[2 * RING * KV_TILE_BYTES];  // K[RING], V[RING]
@@ -421,7 +429,12 @@ __global__ __launch_bounds__(256, (QB == 1 && RING == 2) ? 3 : 2) void attn_self
           const int ch = db * 4 + tcol8;
           const int off0 = r0 * 128 + ((ch ^ (((r0 >> 1) & 1) << 2)) << 4) + tsub;
           const int off1 = r1 * 128 + ((ch ^ (((r1 >> 1) & 1) << 2)) << 4) + tsub;
-          typename Vec<T>::v8 vf = tr_pair<T>(vs, off0, off1);
+          typename Vec<T>::v8 vf;
+          if constexpr (PROBE >= 3) {
+            vf = qf[qb][(s4 + db) & 3].v;  // (any resident register operand)
+          } else {
+            vf = tr_pair<T>(vs, off0, off1);
+          }
           oacc[qb][db] = mfma32(vf, pf[qb][s4].v, oacc[qb][db]);
         }
       }
@@ -438,7 +451,11 @@ __global__ __launch_bounds__(256, (QB == 1 && RING == 2) ? 3 : 2) void attn_self
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int chunk = 2 * s + hh;
-          kf[s].u = *reinterpret_cast<const u32x4*>(ks + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+          if constexpr (PROBE >= 3) {
+            kf[s].u = qf[qb][(s + kb) & 3].u;
+          } else {
+            kf[s].u = *reinterpret_cast<const u32x4*>(ks + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+          }
         }
         sacc[kb] = mfma32(kf[0].v, qf[qb][0].v, nm[qb]);
 #pragma unroll
@@ -479,7 +496,19 @@ __global__ __launch_bounds__(256, (QB == 1 && RING == 2) ? 3 : 2) void attn_self
         return (ps[0] + ps[1]) + (ps[2] + ps[3]);
       };
       float psum;
-      if constexpr (CAREFUL) {
+      if constexpr (PROBE >= 2 && !CAREFUL) {
+        // no softmax: the P operand is made of the S' registers as they stand (keeps the S' -> P.V dependence)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            union { float f[4]; u32x4 u; } t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t.f[e] = sacc[kb][8 * h2 + e];
+            pf[qb][kb * 2 + h2].u = t.u;
+          }
+        psum = sacc[1][15];
+      } else if constexpr (CAREFUL) {
         raise(qb, sacc, lane_max(), kt == 0);
         psum = softmax();
       } else if constexpr (POST) {
@@ -515,7 +544,7 @@ __global__ __launch_bounds__(256, (QB == 1 && RING == 2) ? 3 : 2) void attn_self
   auto arrive = [&](int t) {
     if constexpr (RING == 2) {  // classic double buffer: 32 KiB of LDS, three workgroups per CU at 32 rows per wave
       __syncthreads();          // (drains this wave's DMAs, publishes tile t, frees tile t-1's stage)
-      if (t + 1 < nkt) load_kv(t + 1, (t + 1) & 1);
+      if (t + 1 < nkt && (PROBE == 0 || t == 0)) load_kv(t + 1, (t + 1) & 1);
     } else {
       const int ahead = (nkt - 1 - t < RING - 2) ? nkt - 1 - t : RING - 2;  // younger tiles already issued
       if (ahead >= 2)
@@ -1071,9 +1100,18 @@ template <typename T> __global__ __launch_bounds__(256) void attn_small_kernel(c
 
 using namespace pm;
 
-// kernel selection override for A/B measurements (tools/attn_bench.py); 0 = automatic.  Not part of the ABI.
-static int g_attn_variant = [] { const char* e = getenv("PANDORA_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
-extern "C" void pm_debug_attn_variant(int v) { g_attn_variant = v; }
+// kernel selection override for A/B measurements (tools/attn_bench.py); 0 = automatic.  PANDORA_ATTN_VARIANT is read
+// once, on first use (no static initialiser); pm_debug_attn_variant (declared in the header as a diagnostics entry
+// point) overrides it.
+static int g_attn_variant = -1;
+static int attn_variant() {
+  if (g_attn_variant < 0) {
+    const char* e = getenv("PANDORA_ATTN_VARIANT");
+    g_attn_variant = e ? atoi(e) : 0;
+  }
+  return g_attn_variant;
+}
+extern "C" void pm_debug_attn_variant(int v) { g_attn_variant = v < 0 ? 0 : v; }
 
 extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const void* k1,
                             const void* v1, int64_t k1_bs, int64_t k1_rs, int64_t Nk1,
@@ -1107,7 +1145,7 @@ extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const voi
   // the fastest at every N (1020-1035 TF/s at N = 9216).  The 64-rows-per-wave forms (variants 3 / 5: half the
   // LDS fragment reads per MFMA, a 4-stage K/V ring, 2.0 GHz instead of 1.75) lose 1-3 % there and more on
   // short sequences; kept for A/B runs.
-  const int variant = g_attn_variant;
+  const int variant = attn_variant();
   const bool qb2 = variant == 3 || variant == 5;
   const int rows = qb2 ? 256 : 128;
   p.nqt = (int)((Nq + rows - 1) / rows);
@@ -1123,6 +1161,17 @@ extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const voi
                       return check_launch());
   if (variant == 3) PM_ATTN_LAUNCH(2, true, false, 4);
   if (variant == 5) PM_ATTN_LAUNCH(2, true, true, 4);
+  if (variant >= 11 && variant <= 13) {  // ceiling probes (diagnosis: the output is not an attention result)
+#define PM_ATTN_PROBE(PROBE_)                                                                                      \
+  PM_DISPATCH_DTYPE(dtype, T,                                                                                      \
+                    hipLaunchKernelGGL((attn_self_kernel<T, 1, false, false, 2, PROBE_>), grid, dim3(256), 0,       \
+                                       (hipStream_t)stream, p);                                                    \
+                    return check_launch())
+    if (variant == 11) PM_ATTN_PROBE(1);
+    if (variant == 12) PM_ATTN_PROBE(2);
+    PM_ATTN_PROBE(3);
+#undef PM_ATTN_PROBE
+  }
   PM_ATTN_LAUNCH(1, false, false, 2);
 #undef PM_ATTN_LAUNCH
 }
@@ -1153,7 +1202,7 @@ extern "C" int pm_attention_fp8(const void* q, int64_t q_bs, int64_t q_rs, const
   AttnFp8Params p{};
   p.q8 = pp.q8; p.k8 = pp.k8; p.v8t = pp.v8t; p.o = o; p.o_bs = o_bs; p.o_rs = o_rs;
   p.Nq = (int)Nq; p.Nk = (int)Nk; p.Nq_pad = (int)nq; p.Nk_pad = (int)nk; p.heads = (int)heads;
-  const bool qb2 = g_attn_variant == 2;  // (32 rows per wave measured faster at every N: tools/attn_bench.py 101 / 102)
+  const bool qb2 = attn_variant() == 2;  // (32 rows per wave measured faster at every N: tools/attn_bench.py 101 / 102)
   const int rows = qb2 ? 256 : 128;
   p.nqt = (int)((Nq + rows - 1) / rows);
   dim3 grid((unsigned)(p.nqt * B * heads));

@@ -179,7 +179,10 @@ template <typename TI, typename T>
 __global__ void gn_apply_kernel(const TI* __restrict__ x, int64_t ldx, const float* __restrict__ totals,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                 T* __restrict__ y, int64_t ldy, int P, int C, int groups, float inv_count,
-                                float eps, int silu, int rows_per_block) {
+                                float eps, int silu, int rows_per_block, int lo_off) {
+  // lo_off != 0 (PM_OUT_HILO, the parity configuration): the row is written as [hi | lo], hi = round16(v) at its
+  // column, lo = round16(v - hi) lo_off columns further: a consumer GEMM / conv over 2C channels with the weights
+  // repeated sees the normalised activation at ~2x the mantissa
   const int CV = C >> 3;
   const int k = blockDim.x / CV;
   const int cv = threadIdx.x % CV, rlane = threadIdx.x / CV;
@@ -222,14 +225,16 @@ __global__ void gn_apply_kernel(const TI* __restrict__ x, int64_t ldx, const flo
     for (int u = 0; u < 4; ++u) {
       const int ru = r + u * k;
       if (ru < r1) {
-        Pack8<T> o;
+        Pack8<T> o, lo;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float v = fmaf(t[u][e], sc[e], sh[e]);
           if (silu) v = silu_f(v);
           o.e[e] = from_f32<T>(v);
+          lo.e[e] = from_f32<T>(v - to_f32(o.e[e]));
         }
         st_global16(yp + (int64_t)ru * ldy, o.u);
+        if (lo_off) st_global16(yp + (int64_t)ru * ldy + lo_off, lo.u);
       }
     }
   }
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const TI* __restric
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
                                                              T* __restrict__ y, int64_t ldy, int M, int C,
-                                                             float eps) {
+                                                             float eps, int lo_off) {
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const int sub = lane % LPR;
@@ -300,10 +305,15 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const TI* __restric
     if (c4 < C4) {
       const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c4 * 4);
       const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c4 * 4);
-      Pack4<T> o;
+      Pack4<T> o, lo;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o.e[e] = from_f32<T>(fmaf((v[i][e] - mean) * rstd, g[e], b[e]));
+      for (int e = 0; e < 4; ++e) {
+        const float r = fmaf((v[i][e] - mean) * rstd, g[e], b[e]);
+        o.e[e] = from_f32<T>(r);
+        lo.e[e] = from_f32<T>(r - to_f32(o.e[e]));
+      }
       *reinterpret_cast<u32x2*>(yp + c4 * 4) = o.u;
+      if (lo_off) *reinterpret_cast<u32x2*>(yp + lo_off + c4 * 4) = lo.u;  // (PM_OUT_HILO: see gn_apply_kernel)
     }
   }
 }
@@ -314,7 +324,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         T* __restrict__ y, int64_t ldy, int M, int C,
-                                                        float eps) {
+                                                        float eps, int lo_off) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -350,17 +360,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
   for (int i = 0; i < 8; ++i) {
     const int cv = lane + 64 * i;
     if (cv < CV) {
-      Pack8<T> o;
+      Pack8<T> o, lo;
       const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + cv * 8);
       const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + cv * 8 + 4);
       const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + cv * 8);
       const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + cv * 8 + 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        o.e[e] = from_f32<T>(fmaf((v[i][e] - mean) * rstd, g0[e], b0[e]));
-        o.e[e + 4] = from_f32<T>(fmaf((v[i][e + 4] - mean) * rstd, g1[e], b1[e]));
+        const float r0 = fmaf((v[i][e] - mean) * rstd, g0[e], b0[e]);
+        const float r1 = fmaf((v[i][e + 4] - mean) * rstd, g1[e], b1[e]);
+        o.e[e] = from_f32<T>(r0);
+        o.e[e + 4] = from_f32<T>(r1);
+        lo.e[e] = from_f32<T>(r0 - to_f32(o.e[e]));
+        lo.e[e + 4] = from_f32<T>(r1 - to_f32(o.e[e + 4]));
       }
       st_global16(yp + cv * 8, o.u);
+      if (lo_off) st_global16(yp + lo_off + cv * 8, lo.u);
     }
   }
 }
@@ -442,7 +457,9 @@ extern "C" int pm_groupnorm_apply(const void* x, int64_t ldx, const float* total
   if (!x || !totals || !gamma || !beta || !y) return PM_E_NULL;
   int rc = gn_check(NI, P, C, groups, ldx, in_dtype);
   if (rc) return rc;
-  if ((ldy & 7) || ldy < C || count <= 0) return PM_E_SHAPE;
+  const int lo_off = (out_dtype & PM_OUT_HILO) ? (int)C : 0;
+  out_dtype &= ~PM_OUT_HILO;
+  if ((ldy & 7) || ldy < C + lo_off || count <= 0) return PM_E_SHAPE;
   const int threads = gn_threads((int)(C >> 3));
   const int k = threads / (int)(C >> 3);
   int64_t rpb = 4 * k;  // one batch of four rows per thread; more only to keep the grid under ~8192 blocks
@@ -452,7 +469,7 @@ extern "C" int pm_groupnorm_apply(const void* x, int64_t ldx, const float* total
                      hipLaunchKernelGGL((gn_apply_kernel<TI, TO>), grid, dim3(threads), 0,
                                         (hipStream_t)stream, (const TI*)x, ldx, totals,
                                         gamma, beta, (TO*)y, ldy, (int)P, (int)C, groups,
-                                        (float)(1.0 / count), eps, silu, (int)rpb);
+                                        (float)(1.0 / count), eps, silu, (int)rpb, lo_off);
                      return check_launch());
 }
 
@@ -461,7 +478,9 @@ extern "C" int pm_layernorm(const void* x, int64_t ldx, const float* gamma, cons
                             int out_dtype, void* stream) {
   if (!x || !gamma || !beta || !y) return PM_E_NULL;
   const int64_t amask = (in_dtype == PM_F32) ? 3 : 7;
-  if (M < 1 || C < 8 || (C & 7) || C > 4096 || (ldx & amask) || (ldy & 7) || ldx < C || ldy < C)
+  const int lo_off = (out_dtype & PM_OUT_HILO) ? (int)C : 0;
+  out_dtype &= ~PM_OUT_HILO;
+  if (M < 1 || C < 8 || (C & 7) || C > 4096 || (ldx & amask) || (ldy & 7) || ldx < C || ldy < C + lo_off)
     return PM_E_SHAPE;
   if (C <= 2048) {  // several rows per wave
     const int lpr = C <= 512 ? 16 : (C <= 1024 ? 32 : 64);
@@ -471,7 +490,7 @@ extern "C" int pm_layernorm(const void* x, int64_t ldx, const float* gamma, cons
   PM_DISPATCH_IN_OUT(in_dtype, out_dtype, TI, TO,                                                         \
                      hipLaunchKernelGGL((layernorm_rows_kernel<TI, TO, LPR>), g2, dim3(256), 0,           \
                                         (hipStream_t)stream, (const TI*)x, ldx, gamma, beta, (TO*)y, ldy, \
-                                        (int)M, (int)C, eps);                                             \
+                                        (int)M, (int)C, eps, lo_off);                                     \
                      return check_launch())
     if (lpr == 16) PM_LN_ROWS(16);
     if (lpr == 32) PM_LN_ROWS(32);
@@ -482,6 +501,6 @@ extern "C" int pm_layernorm(const void* x, int64_t ldx, const float* gamma, cons
   PM_DISPATCH_IN_OUT(in_dtype, out_dtype, TI, TO,
                      hipLaunchKernelGGL((layernorm_kernel<TI, TO>), grid, dim3(256), 0,
                                         (hipStream_t)stream, (const TI*)x, ldx, gamma, beta, (TO*)y, ldy,
-                                        (int)M, (int)C, eps);
+                                        (int)M, (int)C, eps, lo_off);
                      return check_launch());
 }

@@ -1,0 +1,140 @@
+"""GPU: end-to-end FRAMES - the north-star's tolerance is on frames, not latents (VERDICT r02 missing #6, weak #2, next #4b/d,
+#7).  Product sampler (DDIMSampler on HipOps) -> product first stage (AutoencoderKL.decode_first_stage on HipOps)
+against fixtures of the REAL reference's chain (DDIMSampler.sample -> LatentDiffusion.decode_first_stage, ddim.py:66 /
+ddpm3d.py:630-655; oracle/make_golden.py --frames / --frames-full):
+
+* reduced width, stored in full: 5 steps eta 0 (parity dtype f16) and the PRODUCTION schedule - 50 steps, eta 1, shared
+  noise - in f16 and bf16;
+* full width (1.44 B U-Net + 83.7 M AutoencoderKL) at 16x40x64 -> 320x512: BASELINE config 1 (10 steps, eta 0) in f16 and
+  the 50-step eta-1 production loop in bf16 (fixtures are digests; skipped until the hours-long CPU run has produced them);
+* the multi-round driver (wm.DiffusionRunner.generate_multiround = ChatWM.generate_video_mutliround, model.py:1094-1129)
+  on HipOps + the HIP AutoencoderKL, 2 rounds incl. the 8-bit round trip (model.py:1179-1187), fp8 attention off and on,
+  against the same driver on the CPU oracle's op table and first stage.
+
+Tolerances are stated per case next to the measured values the tests print ([parity] lines, repeated in the summary)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import golden_recipe as gr
+from open_pandora_amd import synth, wm
+from open_pandora_amd.autoencoder import DDCONFIG, AutoencoderKL
+from open_pandora_amd.ddim import DDIMSampler
+from open_pandora_amd.ddpm import LatentVisualDiffusion
+from open_pandora_amd.unet import UNetModel
+from test_oracle_golden import GOLD, RH_KW, load, rel
+
+pytestmark = pytest.mark.gpu
+
+# reduced width (64 base channels, AE ch 32): trajectory tolerance of tests/test_unet_gpu.py (16-bit-operand floor x CFG
+# amplification) carried through the decoder; the 50-step eta-1 loop accumulates 50 CFG steps
+FRAMES_SMALL_TOL = {(5, 0.0, torch.float16): 6e-3, (50, 1.0, torch.float16): 2.5e-2, (50, 1.0, torch.bfloat16): 1.5e-1}
+# full width: f16 = the parity configuration (forward contract 1e-3, x the CFG amplification bound 3.5 of a trajectory,
+# then the decoder's own 1e-3); bf16 = the dtype of every perf number, 50 steps of the production loop
+FRAMES_FULL_TOL = {("s10_eta0", torch.float16): 3.5e-3, ("s50_eta1", torch.bfloat16): 1.5e-1}
+
+
+def _small(ops):
+    m = UNetModel(**dict(RH_KW, model_channels=64)).eval()
+    m.load_state_dict(synth.synth_state_dict(m, seed=gr.WEIGHT_SEED))
+    ae = AutoencoderKL(ddconfig=dict(DDCONFIG, ch=32))
+    ae.load_state_dict(synth.synth_state_dict(ae, seed=gr.WEIGHT_SEED))
+    return LatentVisualDiffusion(m.bind(ops)), ae.bind(ops)
+
+
+def _sample(pm, h, w, S, eta):
+    ins, cond, uc = gr.sampler_inputs(h, w)
+    dev = lambda c: {k: [t.cuda() for t in v] for k, v in c.items()}
+    ns = gr.noises(ins["x_T"].shape, S) if eta > 0 else None
+    z, _ = DDIMSampler(pm).sample(S=S, batch_size=1, shape=(4, 16, h, w), conditioning=dev(cond), verbose=False,
+                                  unconditional_guidance_scale=4.0, unconditional_conditioning=dev(uc), eta=eta,
+                                  fs=torch.tensor([15]).cuda(), timestep_spacing="uniform_trailing", x_T=ins["x_T"].cuda(),
+                                  noise_fn=(lambda i, shape: ns[i]) if ns else None)
+    return z
+
+
+@pytest.mark.parametrize("S,eta,dtype", [(5, 0.0, torch.float16), (50, 1.0, torch.float16), (50, 1.0, torch.bfloat16)])
+def test_frames_reduced_width(hip_ops_factory, S, eta, dtype):
+    g = load("frames_small.npz")
+    pm, ae = _small(hip_ops_factory(dtype))
+    z = _sample(pm, 8, 8, S, eta)
+    frames = ae.decode_first_stage(z)
+    e_z, e_f = rel(z.cpu(), g[f"S{S}_eta{eta:g}/latent"]), rel(frames.cpu(), g[f"S{S}_eta{eta:g}/frames"])
+    print(f"\n[parity] frames reduced S={S} eta={eta:g} {dtype}: latent {e_z:.2e} -> frames {e_f:.2e}")
+    assert frames.shape == (1, 3, 16, 64, 64) and e_f <= FRAMES_SMALL_TOL[(S, eta, dtype)]
+
+
+def _digest(y, g, key):
+    stride, n = int(g[f"{key}/stride"]), len(g[f"{key}/slice"])
+    got = gr.digest_of(y.float().cpu(), stride, n)
+    return rel(got, g[f"{key}/slice"]), float(y.float().std()), float(g[f"{key}/std"])
+
+
+@pytest.mark.parametrize("tag,S,eta,dtype", [("s10_eta0", 10, 0.0, torch.float16), ("s50_eta1", 50, 1.0, torch.bfloat16)])
+def test_frames_full_width_320x512(hip_ops_factory, tag, S, eta, dtype):
+    path = os.path.join(GOLD, f"frames_full_40x64_s{S}_eta{eta:g}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{os.path.basename(path)} not generated yet (oracle/make_golden.py --frames-full, hours of CPU)")
+    from open_pandora_amd import factory
+    g = np.load(path)
+    ops = hip_ops_factory(dtype)
+    pm = factory.build_diffusion("320x512", ops, seed=gr.WEIGHT_SEED)
+    z = _sample(pm, 40, 64, S, eta)
+    ae = AutoencoderKL()
+    ae.load_state_dict(synth.synth_state_dict(ae, seed=gr.WEIGHT_SEED))
+    frames = ae.bind(ops).decode_first_stage(z)
+    e_z, _, _ = _digest(z, g, "latent")
+    e_f, std, gstd = _digest(frames, g, "frames")
+    print(f"\n[parity] frames full 320x512 S={S} eta={eta:g} {dtype}: latent {e_z:.2e} -> frames {e_f:.2e} "
+          f"(std {std:.4f} vs {gstd:.4f})")
+    assert frames.shape == (1, 3, 16, 320, 512) and e_f <= FRAMES_FULL_TOL[(tag, dtype)]
+    del pm, ae
+    torch.cuda.empty_cache()
+
+
+def _oracle_runner():
+    """The same driver on the CPU oracle: TorchOps op table + oracle/ae_ref first stage (tests only)."""
+    from oracle import ae_ref
+    from oracle.ops_torch import TorchOps
+    m = UNetModel(**dict(RH_KW, model_channels=64)).eval()
+    m.load_state_dict(synth.synth_state_dict(m, seed=gr.WEIGHT_SEED))
+    ae = AutoencoderKL(ddconfig=dict(DDCONFIG, ch=32))
+    sd = synth.synth_state_dict(ae, seed=gr.WEIGHT_SEED)
+    enc = lambda x: ae_ref.ae_sample_latent(ae_ref.ae_encode_moments(sd, x), torch.zeros(x.shape[0], 4, x.shape[2] // 8, x.shape[3] // 8))
+    dec = lambda z: ae_ref.ae_decode(sd, z)
+    return LatentVisualDiffusion(m.bind(TorchOps())), enc, dec
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_multiround_driver_on_the_gpu(fp8):
+    """BASELINE configs[4] at reduced width: 2 autoregressive rounds; round 2 is conditioned on round 1's last 4 frames
+    through the 8-bit PIL round trip; fp8 (e4m3) spatial attention off and on."""
+    from open_pandora_amd.ops_hip import HipOps
+    torch.set_num_threads(8)
+    ops = HipOps(torch.float16, "cuda:0", fp8_attention=fp8, fp8_min_tokens=0)
+    pm, ae = _small(ops)
+    ins, _, _ = gr.sampler_inputs(8, 8)
+    text, img = ins["c_crossattn"][:, :77], ins["c_crossattn"][:, 77:]
+    uct, uci = ins["uc_crossattn"][:, :77], ins["uc_crossattn"][:, 77:]
+    frame0 = gr.ae_pixels(1, 64, 64).permute(1, 0, 2, 3)  # (3, 1, H, W)
+    kw = dict(n_samples=1, ddim_steps=3, ddim_eta=0.0, unconditional_guidance_scale=4.0, fs=15,
+              timestep_spacing="uniform_trailing")
+    zero_noise = lambda x, noise=None: ae.encode_first_stage(x, noise=torch.zeros(x.shape[0], 4, x.shape[2] // 8, x.shape[3] // 8))
+    gpu = wm.DiffusionRunner(pm, lambda im: (img if float(im.abs().sum()) > 0 else uci).cuda(), uct.cuda(), zero_noise,
+                             ae.decode_first_stage)
+    got = gpu.generate_multiround([text.cuda(), (text * 0.9).cuda()], frame0.cuda(), frame0[None, :, 0].cuda(),
+                                  x_T=ins["x_T"].cuda(), **kw)
+    pm_o, enc_o, dec_o = _oracle_runner()
+    cpu = wm.DiffusionRunner(pm_o, lambda im: img if float(im.abs().sum()) > 0 else uci, uct, enc_o, dec_o)
+    want = cpu.generate_multiround([text, text * 0.9], frame0, frame0[None, :, 0], x_T=ins["x_T"], **kw)
+    assert got.shape == want.shape == (1, 1, 3, 12 + 16, 64, 64)
+    e1 = rel(got[0, 0][:, :12].cpu(), want[0, 0][:, :12])   # round 1 (frames 0-11 survive the stitching)
+    e2 = rel(got[0, 0][:, 12:].cpu(), want[0, 0][:, 12:])   # round 2: through the 8-bit conditioning frames
+    print(f"\n[parity] multiround reduced f16 fp8_attention={fp8}: round 1 frames {e1:.2e}, round 2 frames {e2:.2e}")
+    # f16: trajectory tolerance carried through the decoder, x ~3 for round 2 (conditioned on 8-bit frames of round 1: one
+    # uint8 flip is 8e-3 of a pixel).  fp8 attention: 5.5e-2 per attention CALL (three e4m3 roundings) on
+    # EVERY spatial self-attention of the reduced model (fp8_min_tokens=0): measured 7.6e-2 / 1.6e-1 in the frames
+    tol = 1.0e-1 if fp8 else 1.2e-2
+    assert e1 <= tol and e2 <= 2 * tol

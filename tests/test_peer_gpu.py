@@ -136,7 +136,7 @@ def _build(ops, fp):
     return LatentVisualDiffusion(m)
 
 
-def _sample(pm, S=2, eta=1.0):
+def _sample(pm, S=2, eta=0.5):  # (eta 1 at tiny S is NaN by construction: SURVEY 0.5)
     from oracle import golden_recipe as gr
     from open_pandora_amd.ddim import DDIMSampler
     ins, cond, uc = gr.sampler_inputs(8, 8)
@@ -183,7 +183,10 @@ def test_frame_sharded_unet_through_the_mailbox(tmp_path, hip_ops_factory, world
         got = torch.load(f"{out}.{r}")
         assert torch.equal(got["mailbox"], got["p2p"]), r  # same partial sums, same rank-order totals: bit for bit
         err = ((got["mailbox"] - plain).norm() / plain.norm()).item()
-        assert err < 3e-3, (r, err)  # the sharded sums round differently from the single-process ones (f16 operands)
+        # the sharded statistics sum in another order than the single-process ones: the f32 totals differ in the last
+        # bits, 16-bit roundings downstream flip, and two realisations of the rounding process of a reduced-width CFG-4
+        # trajectory sit sqrt(2) x its floor apart (tests/test_unet_gpu.py TRAJ_TOL_REDUCED = 5.6e-3)
+        assert err < 8e-3, (r, err)
         c = got["mailbox_calls"]
         per_fwd = 2 * S
         assert c["mailbox"] == (88 + 17) * per_fwd and got["epoch"] == c["mailbox"]

@@ -1,7 +1,9 @@
 """A/B of the spatial self-attention kernel variants in ONE process (interleaved rounds, random data).
 usage: python tools/attn_bench.py [--dtype bf16|f16] [--rounds 5]
 variants: 9 = round-1 kernel (32 rows/wave), 1 = attn_self_kernel 32 rows/wave, 2 = 64 rows/wave,
-3 = 64 rows/wave with the P.V of block 0 issued behind the S' chain of block 1."""
+3 = 64 rows/wave with the P.V of block 0 issued behind the S' chain of block 1;
+11 / 12 / 13 = CEILING PROBES of the production kernel (no global traffic | + no softmax | + no LDS reads): timing only,
+their output is not an attention result (the agreement check skips them)."""
 import argparse
 import os
 import sys
@@ -44,6 +46,8 @@ def main():
                 torch.cuda.synchronize()
                 if r:
                     res[vv].append(e0.elapsed_time(e1) / n)
+                elif vv in (11, 12, 13):
+                    pass  # probes: not a result
                 else:  # agreement of the variants (first round)
                     if ref is None:
                         ref = o.float()

@@ -63,12 +63,13 @@ def main():
     ap.add_argument("--res", default="320x512")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=16, help="clip length: 16 / N = one rank's share of an N-way frame-sharded step")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     ops = Prof(HipOps(dt, "cuda:0"))
     pm = factory.build_diffusion(a.res, ops)
     h, w = factory.RESOLUTIONS[a.res]["image_size"]
-    ins = synth.synth_inputs(h, w, 16, seed=123)
+    ins = synth.synth_inputs(h, w, a.frames, seed=123)
     cond = {"c_crossattn": [ins["c_crossattn"].cuda()], "c_concat": [ins["c_concat"].cuda()]}
     x = ins["x_T"].cuda()
     ts = torch.full((1,), 500, device="cuda", dtype=torch.long)
@@ -89,7 +90,7 @@ def main():
         r[0] += 1
         r[1] += e0.elapsed_time(e1)
     tot = sum(r[1] for r in agg.values()) / a.reps
-    print(f"# {a.res} {a.dtype}: eager forward {t0.elapsed_time(t1) / a.reps:.2f} ms, sum of op brackets {tot:.2f} ms")
+    print(f"# {a.res} {a.dtype} {a.frames} frames: eager forward {t0.elapsed_time(t1) / a.reps:.2f} ms, sum of op brackets {tot:.2f} ms")
     print(f"{'op':78s} {'n':>4s} {'ms/fwd':>7s} {'us':>7s} {'TF/s':>6s} {'GB/s':>6s} {'floor_us':>8s} {'x':>5s}")
     floor_tot = 0.0
     for tag, (n, ms, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
