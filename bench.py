@@ -102,6 +102,7 @@ class TimedOps:
         ch = o.lib.pm_gemm_kernel_choice(a.shape[0], w.shape[0], k_eff, 2 if act == "geglu" else 0,
                                          1 if f32_loader else 0, o.ws_bytes)
         name = ("gemm_kernel<A_DENSE, f32 operand> (register-staged)" if f32_loader else
+                "gemm256_kernel (256x256, 8 waves, ping-pong phases)" if ch == 2 else
                 "gemm_ring_kernel<A_DENSE>" if ch == 1 else "gemm_kernel<A_DENSE> (128x128, 2 LDS stages, 2 workgroups/CU)")
         self._kern(name, r[1], fl)
         return r[0]
@@ -243,6 +244,36 @@ def compute_scaling(pm_of, unet, ops, dev, reps=6):
         row["projection_2gpu"] = {"cfg_pair": base2 / row["1"]["one_forward_ms"]}
         out[res] = row
     return out
+
+
+def attention_ceiling(ops, dtype, rounds=3, reps=5):
+    """What this chip sustains for the attention kernel's per-tile instruction mix with NO global traffic (the ceiling
+    probe of csrc/attn.hip, pm_debug_attn_variant 11: K/V tiles resident in LDS, same MFMAs / softmax stream / LDS reads),
+    measured beside the production kernel on the same random N = 9216 tensors, interleaved.  The probe's output is not an
+    attention result; only its time is used."""
+    F, N, heads = 16, 9216, 5
+    C = heads * 64
+    qkv = torch.randn(F, N, 3 * C, device=ops.device, dtype=dtype)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    fl = 4.0 * N * N * 64 * heads * F
+    best = {0: 1e9, 11: 1e9}
+    for r in range(rounds + 1):
+        for var in (0, 11):
+            ops.lib.pm_debug_attn_variant(var)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                ops.attention(q, k, v, heads)
+            e1.record()
+            torch.cuda.synchronize()
+            if r:
+                best[var] = min(best[var], e0.elapsed_time(e1) / reps)
+    ops.lib.pm_debug_attn_variant(0)
+    return {"tflops": fl / best[11] / 1e9, "frac_of_peak": fl / best[11] / 1e9 / MFMA_PEAK_TFLOPS,
+            "production_kernel_same_tensors_tflops": fl / best[0] / 1e9,
+            "production_over_ceiling": best[11] / best[0],
+            "what": "the production kernel's per-tile instruction stream with K/V resident in LDS (no global traffic): "
+                    "profiles/r03/attention_ceiling.txt"}
 
 
 def main():
@@ -525,8 +556,10 @@ def main():
                                            ": spatial self-attention, N = 9216 tokens x 16 frames x 5 heads x head dim 64 "
                                            "(576x1024, U-Net level 0)",
                 "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-                "traffic": None, "launches": b["launches"], "avg_launch_ms": b["ms"] / b["launches"],
-                "flops_per_launch": b["flops"] / b["launches"]}
+                "traffic": committed_traffic("attention_n9216"), "launches": b["launches"],
+                "avg_launch_ms": b["ms"] / b["launches"], "flops_per_launch": b["flops"] / b["launches"]}
+            if world == 1 and not a.fp8_attention:
+                out["roofline_attention"]["ceiling"] = attention_ceiling(ops, dt)
         if a.fp8_attention:
             out["config"]["attention"] = "fp8 (e4m3) operands on v_mfma_scale_f32_32x32x64_f8f6f4 for the spatial self-attention"
         if multi is not None:

@@ -11,8 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpandora_mi355x.so")
 STAMP = LIB + ".stamp"
-SOURCES = ["gemm.hip", "lngemm.hip", "attn.hip", "norm.hip", "misc.hip", "peer.hip"]
-HEADERS = ["common.hpp", os.path.join("..", "..", "include", "pandora_mi355x.h")]
+SOURCES = ["gemm.hip", "gemm256.hip", "lngemm.hip", "attn.hip", "norm.hip", "misc.hip", "peer.hip"]
+HEADERS = ["common.hpp", "gemm_common.hpp", os.path.join("..", "..", "include", "pandora_mi355x.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-result"]
 
 

@@ -10,468 +10,9 @@
 // rounded on the way.  LDS rows are 128 B with the 16-byte chunk index XOR-ed by (row & 7) - applied
 // on the source side - so the ds_read_b128 fragment reads spread over the banks.  The epilogue works from
 // registers (operands swapped in the MFMA, W rows interleaved by the loader: epilogue_regs), 16 bytes per lane.
-#include <stdlib.h>
-#include <type_traits>
-#include "common.hpp"
+#include "gemm_common.hpp"
 
 namespace pm {
-
-enum { A_DENSE = 0, A_CONV3X3 = 1, A_CONVT3 = 2, A_CONV3X3_FAST = 3 };
-
-struct GemmParams {
-  const void* A;
-  int64_t lda;  // dense: row stride; conv: elements per pixel
-  const void* Wt;
-  int64_t ldw;
-  const float* bias;
-  const void* R;
-  int64_t ldr;
-  void* C;
-  int64_t ldc;
-  int M, N, K;
-  int act;
-  int out32, res32;  // f32 output / f32 residual (independent)
-  int a_lo;          // PM_FLAG_A_LO (f32 A only): stage a - round16(a), the part the plain pass rounds away
-  int bias_mul;      // PM_FLAG_BIAS_IS_SCALE: `bias` multiplies the accumulator (per-column scale) instead of adding
-  int kwrap;         // PM_FLAG_W_WRAP (dense): W has kwrap = K/2 columns, K-tile kt reads W columns (64 kt) mod kwrap (0: off)
-  int ntiles, mtiles;
-  int splits, ktps;  // split-K: number of K slices and K-tiles per slice
-  float* ws;         // split-K partial slabs [splits][M][N] f32
-  float* colstats;   // optional [ceil(M/64)][Nout][2]: column {sum, sum of squares} of every 64 output rows
-  // conv3x3
-  int Hin, Win, Hv, Wv, Cin, Ho, Wo, stride, ups, pad;  // pad: zero rows/cols before the image (1, or 0)
-  // temporal conv
-  int F, P;
-  const void* halo_lo;
-  const void* halo_hi;
-  const void* zero;
-  int64_t a_bytes;  // conv modes: bytes of the input tensor reachable from A (bound of the buffer descriptor)
-  int64_t tap_a[9], tap_w[9];  // fast 3x3 conv: per tap, byte shift of the A base and byte offset of the W K-tile (channel 0)
-#ifdef PM_RING_PROF
-  long long* prof;  // [grid][8 waves][4] cycle sums (tools/ring_prof.py)
-#endif
-};
-
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
-constexpr int STAGE_LD = 132;            // f32 staging row stride (floats)
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
-
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of tiles so that
-  // neighbouring tiles (same A row panel) share one L2.  Bijective for any nwg.
-  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + (bid >> 3);
-}
-
-// Register-direct epilogue shared by both GEMM kernels.  The MFMAs run with the operands swapped (W
-// fragment as the MFMA "A" operand), so a wave's accumulator tile is C^T: lane (fr, fq) holds output row
-// m = i*16 + fr and, for column block j, the 4 CONSECUTIVE columns 4*fq .. 4*fq+3.  With the loaders'
-// column interleave (cperm below) a block pair (2jp, 2jp+1) gives 8 ADJACENT output columns per lane, so
-// bias / activation / residual / statistics / store all happen in registers with 16-byte accesses: no LDS
-// round trip, no barrier (in-kernel stamps: the LDS-staged epilogue cost ~8600 cycles per 128x128 tile,
-// as much as 12 K-steps of the main loop).
-//   LDS row pr of the W tile holds output column n0 + cperm(pr); GEGLU keeps the natural order (its
-//   [16 value | 16 gate] weight packing IS the block pair).
-__device__ __forceinline__ int cperm(int pr, bool geglu) {
-  const int nn = pr & 15, jb = (pr >> 4) & 3;
-  return geglu ? pr : (pr & ~63) + (jb >> 1) * 32 + (nn >> 2) * 8 + (jb & 1) * 4 + (nn & 3);
-}
-// bias of this lane's 16 output columns, bv[j][r] <-> column block j, column 4*fq + r in MFMA order
-__device__ __forceinline__ void load_bias_regs(const GemmParams& p, float (&bv)[4][4], int n0, int wn, int fq) {
-  const float* bias_p = (p.splits > 1) ? nullptr : p.bias;
-  const bool geglu = p.act == PM_ACT_GEGLU;
-  // column of element (j, 0): the 4 elements r = 0..3 are consecutive columns -> one 16-byte load per j when the
-  // run lies inside [0, N) (N % 4 == 0 on every shape of the path); clamped address + select otherwise
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = geglu ? n0 + wn * 64 + j * 16 + 4 * fq : n0 + wn * 64 + (j >> 1) * 32 + fq * 8 + (j & 1) * 4;
-    if (bias_p != nullptr && (p.N & 3) == 0) {
-      const bool ok = n + 4 <= p.N;
-      const f32x4 t = *reinterpret_cast<const f32x4*>(bias_p + (ok ? n : 0));
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bv[j][r] = ok ? t[r] : 0.f;
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bv[j][r] = (bias_p != nullptr && n + r < p.N) ? bias_p[n + r] : 0.f;
-    }
-  }
-}
-// Straight-line store pass of one epilogue flavour (OUT32: f32 output; RES: 0 none, 1 16-bit, 2 f32 residual).
-// The generic epilogue below carries every flavour behind runtime branches, replicated 8x by the unrolled
-// (row block, column pair) loops: ~6000 cycles per tile by the in-kernel stamps (branch-bound and far beyond
-// the instruction cache).  Here the flavour is chosen ONCE per tile, addresses of dead lanes are clamped
-// (so the residual loads of a half tile issue back to back, unconditionally) and only the stores are
-// predicated.  Needs N % 8 == 0 and 16-byte-aligned rows (checked by the caller).
-template <typename T, bool OUT32, int RES>
-__device__ __forceinline__ void store_fast(const GemmParams& p, f32x4 (&acc)[4][4], void* cbase, int64_t ldc,
-                                           int mrow0, int ncol0, int nout, int fr, int fq, bool stats,
-                                           float (&cs)[2][8], float (&cq)[2][8]) {
-  int ncl[2];
-  bool nok[2];
-#pragma unroll
-  for (int jp = 0; jp < 2; ++jp) {
-    const int n = ncol0 + jp * 32 + fq * 8;
-    nok[jp] = n < nout;
-    ncl[jp] = nok[jp] ? n : 0;
-  }
-#pragma unroll
-  for (int ih = 0; ih < 2; ++ih) {  // two row-block halves: bounds the residual registers in flight
-    u32x4 r16[2][2];
-    f32x4 r32[2][2][2];
-    int64_t rowoff[2];
-    bool mok[2];
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-      const int m = mrow0 + (ih * 2 + ii) * 16 + fr;
-      mok[ii] = m < p.M;
-      rowoff[ii] = mok[ii] ? m : 0;
-#pragma unroll
-      for (int jp = 0; jp < 2; ++jp) {
-        if constexpr (RES == 1) {
-          r16[ii][jp] = ld_global16(reinterpret_cast<const T*>(p.R) + rowoff[ii] * p.ldr + ncl[jp]);
-        } else if constexpr (RES == 2) {
-          const float* rp = reinterpret_cast<const float*>(p.R) + rowoff[ii] * p.ldr + ncl[jp];
-          r32[ii][jp][0] = *reinterpret_cast<const f32x4*>(rp);
-          r32[ii][jp][1] = *reinterpret_cast<const f32x4*>(rp + 4);
-        }
-      }
-    }
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-      const int i = ih * 2 + ii;
-#pragma unroll
-      for (int jp = 0; jp < 2; ++jp) {
-        float v[8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = acc[i][2 * jp][r];
-          v[4 + r] = acc[i][2 * jp + 1][r];
-        }
-        if constexpr (RES == 1) {
-          Pack8<T> rv;
-          rv.u = r16[ii][jp];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += to_f32(rv.e[e]);
-        } else if constexpr (RES == 2) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] += r32[ii][jp][0][e];
-            v[e + 4] += r32[ii][jp][1][e];
-          }
-        }
-        const bool ok = mok[ii] && nok[jp];
-        if (stats) {  // (wave-uniform)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float x = ok ? v[e] : 0.f;
-            cs[jp][e] += x;
-            cq[jp][e] = fmaf(x, x, cq[jp][e]);
-          }
-        }
-        if (ok) {
-          if constexpr (OUT32) {
-            float* cptr = reinterpret_cast<float*>(cbase) + rowoff[ii] * ldc + ncl[jp];
-            *reinterpret_cast<f32x4*>(cptr) = f32x4{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(cptr + 4) = f32x4{v[4], v[5], v[6], v[7]};
-          } else {
-            Pack8<T> ov;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ov.e[e] = from_f32<T>(v[e]);
-            st_global16(reinterpret_cast<T*>(cbase) + rowoff[ii] * ldc + ncl[jp], ov.u);
-          }
-        }
-      }
-    }
-  }
-}
-
-// Residual prefetch: when the epilogue is "+ bias, + residual, store" (no activation, unsplit, 8-column vectors),
-// the accumulators START from the residual instead of zero: its loads are issued at tile start and land behind the
-// K loop instead of stalling the epilogue (these GEMMs stream A, residual and output once: HBM-latency-bound), and
-// the epilogue then skips the add.  Returns whether it did (the caller zero-fills otherwise).
-template <typename T>
-__device__ __forceinline__ bool residual_into_acc(const GemmParams& p, f32x4 (&acc)[4][4], int m0, int n0, int wm,
-                                                  int wn, int fr, int fq) {
-  if (p.R == nullptr || p.splits > 1 || p.act != PM_ACT_NONE || p.bias_mul || (p.N & 7) || (p.ldc & 7) || (p.ldr & 7)) return false;
-  const bool f32res = p.res32 != 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int m = m0 + wm * 64 + i * 16 + fr;
-    if (m > p.M - 1) m = p.M - 1;
-#pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
-      int n = n0 + wn * 64 + jp * 32 + fq * 8;
-      if (n > p.N - 8) n = p.N - 8;
-      if (f32res) {
-        const float* rp = reinterpret_cast<const float*>(p.R) + (int64_t)m * p.ldr + n;
-        acc[i][2 * jp] = *reinterpret_cast<const f32x4*>(rp);
-        acc[i][2 * jp + 1] = *reinterpret_cast<const f32x4*>(rp + 4);
-      } else {
-        Pack8<T> rv;
-        rv.u = ld_global16(reinterpret_cast<const T*>(p.R) + (int64_t)m * p.ldr + n);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          acc[i][2 * jp][r] = to_f32(rv.e[r]);
-          acc[i][2 * jp + 1][r] = to_f32(rv.e[4 + r]);
-        }
-      }
-    }
-  }
-  return true;
-}
-
-// rows m0 + wm*64 + i*16 + fr, columns n0 + wn*64 + ...; sblock = index of this wave's 64-row block in colstats
-template <typename T, bool FAST = true>
-__device__ __forceinline__ void epilogue_regs(const GemmParams& p, f32x4 (&acc)[4][4], const float (&bv)[4][4],
-                                              int m0, int n0, int wm, int wn, int fr, int fq, int sblock,
-                                              int split, bool res_done = false) {
-  const bool partial = p.splits > 1;
-  // The MFMAs ran with the operands swapped (W fragment as "A"), so the accumulator tile is C^T: lane
-  // (fr, fq) holds row m = i*16 + fr and, for column block j, the 4 CONSECUTIVE columns 4*fq .. 4*fq+3.
-  // With the loader's column interleave a block pair (2jp, 2jp+1) gives 8 adjacent columns per lane:
-  // bias / activation / residual / statistics / store all happen in registers with 16-byte accesses -
-  // no LDS round trip, no barrier (the LDS-staged epilogue cost ~8600 cycles per tile = 12 K-steps).
-  const int act = partial ? PM_ACT_NONE : p.act;
-  const bool geglu = (act == PM_ACT_GEGLU);
-  const int nout = geglu ? (p.N >> 1) : p.N;
-  T* __restrict__ Cg = reinterpret_cast<T*>(p.C);
-  const T* __restrict__ Rg = (partial || p.res32 || res_done) ? nullptr : reinterpret_cast<const T*>(p.R);
-  float* __restrict__ Cf = partial ? p.ws + (int64_t)split * p.M * p.N : reinterpret_cast<float*>(p.C);
-  const float* __restrict__ Rf = (partial || !p.res32 || res_done) ? nullptr : reinterpret_cast<const float*>(p.R);
-  const bool out32 = partial || p.out32 != 0;
-  const int64_t ldc = partial ? p.N : p.ldc;
-  const bool want_stats = (p.colstats != nullptr) && !partial;
-  // ---- fast flavours (every shape of the U-Net except N % 8 != 0, i.e. the 4-channel output conv) ----
-  if (FAST && !geglu && (nout & 7) == 0 && (ldc & 7) == 0 && (p.R == nullptr || (p.ldr & 7) == 0)) {
-    // bias and activation in place (one uniform branch per activation, not per element group)
-    if (p.bias_mul && !partial) {  // (uniform) per-column scale, e.g. the softmax scale on the q third of a q|k|v projection
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[i][j][r] *= bv[j][r];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[i][j][r] += bv[j][r];
-    }
-    if (act == PM_ACT_SILU) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[i][j][r] = silu_f(acc[i][j][r]);
-    } else if (act == PM_ACT_GELU) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[i][j][r] = gelu_erf_f(acc[i][j][r]);
-    }
-    float cs[2][8], cq[2][8];
-#pragma unroll
-    for (int jp = 0; jp < 2; ++jp)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) cs[jp][e] = cq[jp][e] = 0.f;
-    const int mrow0 = m0 + wm * 64, ncol0 = n0 + wn * 64;
-    void* cb = out32 ? static_cast<void*>(Cf) : static_cast<void*>(Cg);
-    if (out32) {
-      if (Rf != nullptr)
-        store_fast<T, true, 2>(p, acc, cb, ldc, mrow0, ncol0, nout, fr, fq, want_stats, cs, cq);
-      else
-        store_fast<T, true, 0>(p, acc, cb, ldc, mrow0, ncol0, nout, fr, fq, want_stats, cs, cq);
-    } else {
-      if (Rf != nullptr)
-        store_fast<T, false, 2>(p, acc, cb, ldc, mrow0, ncol0, nout, fr, fq, want_stats, cs, cq);
-      else if (Rg != nullptr)
-        store_fast<T, false, 1>(p, acc, cb, ldc, mrow0, ncol0, nout, fr, fq, want_stats, cs, cq);
-      else
-        store_fast<T, false, 0>(p, acc, cb, ldc, mrow0, ncol0, nout, fr, fq, want_stats, cs, cq);
-    }
-    if (want_stats) {  // column sums of this wave's 64 rows: in-lane over i, then a fixed xor tree over fr
-#pragma unroll
-      for (int jp = 0; jp < 2; ++jp)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-#pragma unroll
-          for (int o = 8; o > 0; o >>= 1) {
-            cs[jp][e] += __shfl_xor(cs[jp][e], o, 64);
-            cq[jp][e] += __shfl_xor(cq[jp][e], o, 64);
-          }
-        }
-      if (fr == 0 && sblock * 64 < p.M) {  // (a ragged last tile has no second block)
-#pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-          const int n = ncol0 + jp * 32 + fq * 8;
-          if (n < nout) {
-            float* dst = p.colstats + ((int64_t)sblock * nout + n) * 2;
-#pragma unroll
-            for (int e = 0; e < 8; e += 2)
-              *reinterpret_cast<f32x4*>(dst + 2 * e) = f32x4{cs[jp][e], cq[jp][e], cs[jp][e + 1], cq[jp][e + 1]};
-          }
-        }
-      }
-    }
-    return;
-  }
-  if (FAST && geglu && (nout & 3) == 0 && (ldc & 3) == 0) {
-    // fast GEGLU flavour: value block 2jj, gate block 2jj+1 (weights packed [16 value | 16 gate]); a lane owns
-    // 4 adjacent output columns per pair: straight-line bias, erf-GELU gate, product, 8-byte stores
-    const int mrow0 = m0 + wm * 64;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = mrow0 + i * 16 + fr;
-      const int64_t mrow = m < p.M ? m : 0;
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int n = (n0 >> 1) + wn * 32 + jj * 16 + 4 * fq;
-        Pack4<T> ov;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          ov.e[r] = from_f32<T>((acc[i][2 * jj][r] + bv[2 * jj][r]) * gelu_erf_f(acc[i][2 * jj + 1][r] + bv[2 * jj + 1][r]));
-        if (m < p.M && n < nout) *reinterpret_cast<u32x2*>(Cg + mrow * ldc + n) = ov.u;
-      }
-    }
-    return;
-  }
-  if (geglu) {
-    // value block 2jj, gate block 2jj+1 (weights packed [16 value | 16 gate]): 4 output columns per lane
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wm * 64 + i * 16 + fr;
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int n = (n0 >> 1) + wn * 32 + jj * 16 + 4 * fq;
-        if (m < p.M && n < nout) {
-          Pack4<T> ov;
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            ov.e[r] = from_f32<T>((acc[i][2 * jj][r] + bv[2 * jj][r]) * gelu_erf_f(acc[i][2 * jj + 1][r] + bv[2 * jj + 1][r]));
-          T* cptr = Cg + (int64_t)m * ldc + n;
-          if (n + 4 <= nout && ((ldc & 3) == 0))
-            *reinterpret_cast<u32x2*>(cptr) = ov.u;
-          else
-            for (int e = 0; e < 4 && n + e < nout; ++e) cptr[e] = ov.e[e];
-        }
-      }
-    }
-  } else {
-    float cs[2][8], cq[2][8];
-#pragma unroll
-    for (int jp = 0; jp < 2; ++jp)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) cs[jp][e] = cq[jp][e] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wm * 64 + i * 16 + fr;
-#pragma unroll
-      for (int jp = 0; jp < 2; ++jp) {
-        const int n = n0 + wn * 64 + jp * 32 + fq * 8;
-        if (m < p.M && n < nout) {
-          float v[8];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] = (p.bias_mul && !partial) ? acc[i][2 * jp][r] * bv[2 * jp][r] : acc[i][2 * jp][r] + bv[2 * jp][r];
-            v[4 + r] = (p.bias_mul && !partial) ? acc[i][2 * jp + 1][r] * bv[2 * jp + 1][r]
-                                                : acc[i][2 * jp + 1][r] + bv[2 * jp + 1][r];
-          }
-          if (act == PM_ACT_SILU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-          } else if (act == PM_ACT_GELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
-          }
-          const bool fullr = (n + 8 <= nout);
-          if (Rf != nullptr) {
-            const float* rptr = Rf + (int64_t)m * p.ldr + n;
-            if (fullr && ((p.ldr & 3) == 0)) {
-              const f32x4 r0 = *reinterpret_cast<const f32x4*>(rptr);
-              const f32x4 r1 = *reinterpret_cast<const f32x4*>(rptr + 4);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                v[e] += r0[e];
-                v[e + 4] += r1[e];
-              }
-            } else {
-              for (int e = 0; e < 8 && n + e < nout; ++e) v[e] += rptr[e];
-            }
-          } else if (Rg != nullptr) {
-            const T* rptr = Rg + (int64_t)m * p.ldr + n;
-            if (fullr && ((p.ldr & 7) == 0)) {
-              Pack8<T> rv;
-              rv.u = ld_global16(rptr);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += to_f32(rv.e[e]);
-            } else {
-              for (int e = 0; e < 8 && n + e < nout; ++e) v[e] += to_f32(rptr[e]);
-            }
-          }
-          if (want_stats) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if (n + e < nout) {
-                cs[jp][e] += v[e];
-                cq[jp][e] = fmaf(v[e], v[e], cq[jp][e]);
-              }
-          }
-          if (out32) {
-            float* cptr = Cf + (int64_t)m * ldc + n;
-            if (fullr && ((ldc & 3) == 0)) {
-              *reinterpret_cast<f32x4*>(cptr) = f32x4{v[0], v[1], v[2], v[3]};
-              *reinterpret_cast<f32x4*>(cptr + 4) = f32x4{v[4], v[5], v[6], v[7]};
-            } else {
-              for (int e = 0; e < 8 && n + e < nout; ++e) cptr[e] = v[e];
-            }
-          } else {
-            T* cptr = Cg + (int64_t)m * ldc + n;
-            if (fullr && ((ldc & 7) == 0)) {
-              Pack8<T> ov;
-#pragma unroll
-              for (int e = 0; e < 8; ++e) ov.e[e] = from_f32<T>(v[e]);
-              st_global16(cptr, ov.u);
-            } else {
-              for (int e = 0; e < 8 && n + e < nout; ++e) cptr[e] = from_f32<T>(v[e]);
-            }
-          }
-        }
-      }
-    }
-    if (want_stats) {  // column sums of this wave's 64 rows: in-lane over i, then a fixed xor tree over fr
-#pragma unroll
-      for (int jp = 0; jp < 2; ++jp)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-#pragma unroll
-          for (int o = 8; o > 0; o >>= 1) {
-            cs[jp][e] += __shfl_xor(cs[jp][e], o, 64);
-            cq[jp][e] += __shfl_xor(cq[jp][e], o, 64);
-          }
-        }
-      if (fr == 0 && sblock * 64 < p.M) {  // (a ragged last tile has no second block)
-#pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-          const int n = n0 + wn * 64 + jp * 32 + fq * 8;
-          float* dst = p.colstats + ((int64_t)sblock * nout + n) * 2;
-          for (int e = 0; e < 8 && n + e < nout; ++e) {
-            dst[2 * e] = cs[jp][e];
-            dst[2 * e + 1] = cq[jp][e];
-          }
-        }
-      }
-    }
-  }
-}
 
 // 128x128 tile, 4 waves, 2 LDS stages, 2 workgroups per CU (any shape, split-K, f32 A).
 template <typename T, int AMODE, bool A32>
@@ -1591,6 +1132,8 @@ extern "C" int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, c
   if (K % BK) return PM_E_SHAPE;  // all Linear layers on the path have K % 64 == 0
   plan_split(p, workspace, workspace_bytes);
   if (p.colstats != nullptr && p.splits > 1 && ((p.ldc & 3) || (p.R != nullptr && (p.ldr & 3)))) return PM_E_SHAPE;
+  if (gemm256_wanted(p, flags, num_cus()))  // large MFMA-bound shapes: 256x256 tiles, 8-phase ping-pong (gemm256.hip)
+    PM_DISPATCH_DTYPE(dtype, T, return (launch_gemm256<T>(p, num_cus(), (hipStream_t)stream)));
   PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_DENSE>(p, flags, (hipStream_t)stream)));
 }
 
@@ -1686,6 +1229,7 @@ extern "C" int pm_gemm_kernel_choice(int64_t M, int64_t N, int64_t K, int act, i
   p.ntiles = (int)((N + BN - 1) / BN);
   static float dummy_ws;  // (only its non-NULLness matters to plan_split)
   plan_split(p, workspace_bytes ? &dummy_ws : nullptr, workspace_bytes);
+  if (gemm256_wanted(p, flags, num_cus())) return 2;
   return (g_ring == 2 || (g_ring == 1 && prefer_ring(A_DENSE, p))) ? 1 : 0;
 }
 

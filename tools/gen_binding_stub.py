@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from open_pandora_amd import capi  # noqa: E402
 
 NAMES = {ctypes.c_void_p: "c_void_p", ctypes.c_int64: "c_int64", ctypes.c_int: "c_int", ctypes.c_float: "c_float",
-         ctypes.c_double: "c_double", ctypes.c_size_t: "c_size_t", ctypes.c_char_p: "c_char_p"}
+         ctypes.c_double: "c_double", ctypes.c_size_t: "c_size_t", ctypes.c_char_p: "c_char_p", None: "None"}
 
 
 def stub():
