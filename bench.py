@@ -186,9 +186,10 @@ def cpu_baseline(unet, res, ins):
             "sample": f"1 of the 2 U-Net forwards of one CFG DDIM step at {res} (f32 oracle, {dt:.1f} s), x2 per step"}
 
 
-def committed_traffic(res):
-    """HBM-side bytes of the dominant kernels from the committed PMC summary (separate rocprofv3 --pmc passes, gfx950
-    FETCH_SIZE correction applied there) - only when it was taken with the library sources of THIS run."""
+def committed_traffic(res, fam="gemm"):
+    """HBM-side bytes per launch of a kernel family from the committed PMC summary (separate rocprofv3 --pmc passes over
+    one eager forward, gfx950 FETCH_SIZE correction applied there: tools/pmc_traffic.py) - only when it was taken with
+    the library sources of THIS run; otherwise null."""
     path = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
     try:
         from open_pandora_amd import build as _b
@@ -196,8 +197,8 @@ def committed_traffic(res):
             t = json.load(f)
         if t.get("lib_digest") != _b._digest():
             return None
-        return t.get(res)
-    except (OSError, ValueError):
+        return t[res][fam]["bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
         return None
 
 
@@ -510,7 +511,9 @@ def main():
                                                                                         if x["ms"] > 0 else 0.0)}
                                              for n, x in r["kern"].items()}}
             return {"bound": "mfma", "kernel": KERNELS[fam], "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": committed_traffic(r["res"]),
+                    "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": committed_traffic(r["res"], fam),
+                    "algorithmic_bytes_per_launch": (r["families"][fam]["algorithmic_TBps"] * 1e12 * v["ms"] * 1e-3
+                                                     / max(1, v["launches"])),
                     "dominant_kernel": dom, "sequential_step_ms": r["seq_step_ms"],
                     "hbm_view": {"achieved": r["families"][fam]["algorithmic_TBps"], "peak": 8.0, "unit": "TB/s",
                                  "frac": r["families"][fam]["frac_of_hbm_8TBps"],
@@ -556,7 +559,7 @@ def main():
                                            ": spatial self-attention, N = 9216 tokens x 16 frames x 5 heads x head dim 64 "
                                            "(576x1024, U-Net level 0)",
                 "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-                "traffic": committed_traffic("attention_n9216"), "launches": b["launches"],
+                "traffic": committed_traffic("attention_n9216", "attention"), "launches": b["launches"],
                 "avg_launch_ms": b["ms"] / b["launches"], "flops_per_launch": b["flops"] / b["launches"]}
             if world == 1 and not a.fp8_attention:
                 out["roofline_attention"]["ceiling"] = attention_ceiling(ops, dt)

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collect the round's measurement artefacts on the GPU box into gpurun_out/$1 (copy what is to be judged into
-# profiles/$1 afterwards).  usage: tools/collect_profiles.sh r02
+# profiles/$1 afterwards).  usage: tools/collect_profiles.sh r03
 set -u
-R=${1:-r02}; O=gpurun_out/$R; mkdir -p $O
+R=${1:-r03}; O=gpurun_out/$R; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 PMC_SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
 # 1. the driver's command, plain and under rocprofv3 --kernel-trace --stats
@@ -28,9 +28,21 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_calib --
 python3 tools/pmc_table.py $O/pmc_calib >> $O/fetch_calib.txt
 python3 tools/lngemm_bench.py --reps 30 > $O/lngemm_ab.txt 2>/dev/null
 # 4. attention A/B (bf16 variants + fp8) and its SQ counters
-python3 tools/attn_bench.py --rounds 7 --variants 9,1,3,5,101 > $O/attention_ab.txt 2>/dev/null
+python3 tools/attn_bench.py --rounds 7 --variants 9,1,3,5,11,12,13,101 > $O/attention_ab.txt 2>/dev/null
 rocprofv3 --kernel-trace --pmc $PMC_SQ --output-format csv -d $O/pmc_attn -- python3 tools/attn_pmc.py > /dev/null 2>&1
 python3 tools/pmc_table.py $O/pmc_attn > $O/pmc_attention_n9216.txt
+# 4b. HBM-side bytes per launch of the families of one eager forward (FETCH_SIZE and WRITE_SIZE passes of their own) and of
+#     the N = 9216 attention -> pmc_traffic.json (bench.py quotes it as roofline.traffic while the sources match)
+args=""
+for res in 320x512 576x1024; do
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/tf_$res -- python3 tools/fwd_only.py 1 $res > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/tw_$res -- python3 tools/fwd_only.py 1 $res > /dev/null 2>&1
+  args="$args $res=$O/tf_$res,$O/tw_$res"
+done
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/tf_attn -- python3 tools/attn_pmc.py 9216 prod > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/tw_attn -- python3 tools/attn_pmc.py 9216 prod > /dev/null 2>&1
+python3 tools/pmc_traffic.py $O/pmc_traffic.json $args attention_n9216=$O/tf_attn,$O/tw_attn > /dev/null
+rm -rf $O/tf_* $O/tw_*
 # 5. configs[2] alone, configs[4] (fp8 attention, 5 rounds)
 python3 bench.py --steps 10 --warmup 3 --cpu-baseline off --fp8-attention --multiround 5 > $O/bench_fp8_multiround.json 2>/dev/null
 rm -rf $O/bench_trace $O/fwd_* $O/pmc_sq $O/pmc_fetch $O/pmc_write $O/pmc_calib $O/pmc_attn
