@@ -6,7 +6,7 @@ ddpm3d.py:630-655; oracle/make_golden.py --frames / --frames-full):
 * reduced width, stored in full: 5 steps eta 0 (parity dtype f16) and the PRODUCTION schedule - 50 steps, eta 1, shared
   noise - in f16 and bf16;
 * full width (1.44 B U-Net + 83.7 M AutoencoderKL) at 16x40x64 -> 320x512: BASELINE config 1 (10 steps, eta 0) in f16 and
-  the 50-step eta-1 production loop in bf16 (fixtures are digests; skipped until the hours-long CPU run has produced them);
+  the 50-step eta-1 production loop in bf16 (fixtures are digests of the reference's latent and frames: hours of CPU each);
 * the multi-round driver (wm.DiffusionRunner.generate_multiround = ChatWM.generate_video_mutliround, model.py:1094-1129)
   on HipOps + the HIP AutoencoderKL, 2 rounds incl. the 8-bit round trip (model.py:1179-1187), fp8 attention off and on,
   against the same driver on the CPU oracle's op table and first stage.
@@ -30,10 +30,10 @@ pytestmark = pytest.mark.gpu
 
 # reduced width (64 base channels, AE ch 32): trajectory tolerance of tests/test_unet_gpu.py (16-bit-operand floor x CFG
 # amplification) carried through the decoder; the 50-step eta-1 loop accumulates 50 CFG steps
-FRAMES_SMALL_TOL = {(5, 0.0, torch.float16): 6e-3, (50, 1.0, torch.float16): 2.5e-2, (50, 1.0, torch.bfloat16): 1.5e-1}
+FRAMES_SMALL_TOL = {(5, 0.0, torch.float16): 6e-3, (50, 1.0, torch.float16): 8e-3, (50, 1.0, torch.bfloat16): 6e-2}  # measured 3.4e-3 / 3.1e-3 / 3.0e-2
 # full width: f16 = the parity configuration (forward contract 1e-3, x the CFG amplification bound 3.5 of a trajectory,
 # then the decoder's own 1e-3); bf16 = the dtype of every perf number, 50 steps of the production loop
-FRAMES_FULL_TOL = {("s10_eta0", torch.float16): 3.5e-3, ("s50_eta1", torch.bfloat16): 1.5e-1}
+FRAMES_FULL_TOL = {("s10_eta0", torch.float16): 3.5e-3, ("s50_eta1", torch.bfloat16): 3e-2}  # measured 1.34e-3 / 8.95e-3
 
 
 def _small(ops):
