@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the round's measurement artefacts on the GPU box into gpurun_out/$1 (copy what is to be judged into
 # profiles/$1 afterwards).  usage: tools/collect_profiles.sh r03 [part]   part = a (bench, kernel stats, tables, A/Bs)
-# | b (PMC passes) | all.  Every command runs under its own timeout and scratch directories are removed as soon as they
+# | b (PMC passes of the probe launches) | c (PMC traffic passes over one forward) | all.  Every command runs under its own timeout and scratch directories are removed as soon as they
 # are summarised, so a slow pass costs its own result only.
 set -u
 R=${1:-r03}; PART=${2:-all}; O=gpurun_out/$R; mkdir -p $O
@@ -40,12 +40,16 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE $INC --output-format csv -
 python3 tools/pmc_table.py $O/pmc_calib >> $O/fetch_calib.txt; rm -rf $O/pmc_calib
 timeout 600 rocprofv3 --kernel-trace --pmc $PMC_SQ $INC --output-format csv -d $O/pmc_attn -- python3 tools/attn_pmc.py > /dev/null 2>&1
 python3 tools/pmc_table.py $O/pmc_attn > $O/pmc_attention_n9216.txt; rm -rf $O/pmc_attn
+fi
+if [ $PART = c ] || [ $PART = all ]; then
+INC="--kernel-include-regex pm"
 # 6. HBM-side bytes per launch of the families of one eager forward (FETCH_SIZE and WRITE_SIZE passes of their own) and of
 #    the N = 9216 attention -> pmc_traffic.json (bench.py quotes it as roofline.traffic while the sources match)
 args=""
 for res in 320x512 576x1024; do
-  timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE $INC --output-format csv -d $O/tf_$res -- python3 tools/fwd_only.py 1 $res > /dev/null 2>&1
-  timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE $INC --output-format csv -d $O/tw_$res -- python3 tools/fwd_only.py 1 $res > /dev/null 2>&1
+  date
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE $INC --output-format csv -d $O/tf_$res -- python3 tools/fwd_only.py 1 $res > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE $INC --output-format csv -d $O/tw_$res -- python3 tools/fwd_only.py 1 $res > /dev/null 2>&1
   args="$args $res=$O/tf_$res,$O/tw_$res"
 done
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE $INC --output-format csv -d $O/tf_attn -- python3 tools/attn_pmc.py 9216 prod > /dev/null 2>&1
