@@ -36,6 +36,10 @@ import torch.distributed as dist
 from . import capi
 
 
+class PeerUnavailable(RuntimeError):
+    """The frame group cannot use peer mailboxes (raised on EVERY rank of the group, never on one alone)."""
+
+
 class PeerMailbox:
     """hipIpc-mapped mailboxes of one frame group (csrc/peer.hip, include/pandora_mi355x.h `pm_peer_*`): the 256-byte
     GroupNorm partial sums to every rank and the boundary frames to the two neighbours travel as direct peer writes
@@ -53,34 +57,85 @@ class PeerMailbox:
         self.timeout_s = float(os.environ.get("PANDORA_PEER_TIMEOUT_S", "5"))
 
     def _create(self, halo_bytes):
+        """Collective.  Either every rank of the group ends up with every mailbox mapped, or every rank raises
+        PeerUnavailable (a rank that cannot allocate / export / map says so in the handle exchange instead of raising
+        alone: its peers would otherwise wait for it in the collectives below)."""
         self.close()
         torch.cuda.synchronize(self.ops.device)
         self.halo_max = int(halo_bytes)
         nbytes = self.lib.pm_peer_mailbox_bytes(self.world, self.NSTAT_MAX, self.halo_max)
         base, fg = ctypes.c_void_p(), ctypes.c_int()
         handle = ctypes.create_string_buffer(64)
-        capi.check(self.lib.pm_peer_create(nbytes, ctypes.byref(base), handle, ctypes.byref(fg)), "pm_peer_create")
+        rc = self.lib.pm_peer_create(nbytes, ctypes.byref(base), handle, ctypes.byref(fg))
+        if rc == 0 and os.environ.get("PANDORA_PEER_INJECT_FAIL") == str(self.rank):  # fault injection (tests/test_peer_gpu.py)
+            self.lib.pm_peer_destroy(base)
+            rc = -1
+        infos = [None] * self.world
+        dist.all_gather_object(infos, (int(rc), bytes(handle.raw)), group=self.group)
+        if any(i[0] != 0 for i in infos):
+            if rc == 0:
+                self.lib.pm_peer_destroy(base)
+            raise PeerUnavailable(f"pm_peer_create failed on rank(s) {[r for r, i in enumerate(infos) if i[0] != 0]}")
         self.base, self.fine_grained = base, bool(fg.value)
-        handles = [None] * self.world
-        dist.all_gather_object(handles, bytes(handle.raw), group=self.group)
         self.peers = (ctypes.c_void_p * self.world)()
+        bad = 0
         for r in range(self.world):
             if r != self.rank:
                 p = ctypes.c_void_p()
-                capi.check(self.lib.pm_peer_open(handles[r], ctypes.byref(p)), f"pm_peer_open (rank {r})")
+                if self.lib.pm_peer_open(infos[r][1], ctypes.byref(p)) != 0:
+                    bad = 1
+                    continue
                 self.peers[r] = p
-        dist.barrier(group=self.group)  # every mailbox is mapped everywhere before the first write
+        flags = [None] * self.world
+        dist.all_gather_object(flags, bad, group=self.group)  # (also: every mailbox is mapped everywhere before the first write)
+        if any(flags):
+            self._release()
+            raise PeerUnavailable(f"pm_peer_open failed on rank(s) {[r for r, f in enumerate(flags) if f]}")
+
+    def commission(self):
+        """Collective go / no-go at construction: map the mailboxes and run ONE exchange of known values with a short
+        timeout.  -> True on every rank, or False on every rank (the group then keeps the torch.distributed form of
+        the two exchanges).  A platform where peer writes / system-scope atomics between the group's devices do not
+        work shows up here as a timed-out or wrong exchange instead of as a hang in the middle of a clip."""
+        ok, why = 1, ""
+        try:
+            self._create(0)
+        except PeerUnavailable as exc:  # (raised on every rank)
+            return False, str(exc)
+        keep, self.timeout_s = self.timeout_s, min(self.timeout_s, 2.0)
+        try:
+            mine = torch.full((8,), float(self.rank + 1), dtype=torch.float32, device=self.ops.device)
+            tot, _, _ = self.exchange(mine)
+            torch.cuda.synchronize(self.ops.device)
+            want = float(self.world * (self.world + 1) // 2)
+            self.check()
+            if not bool((tot == want).all()):
+                ok, why = 0, f"self-test exchange returned {tot.tolist()} instead of {want}"
+        except capi.PandoraKernelError as exc:
+            ok, why = 0, str(exc)
+        finally:
+            self.timeout_s = keep
+        res = [None] * self.world
+        dist.all_gather_object(res, (ok, why), group=self.group)
+        if all(r[0] for r in res):
+            return True, ""
+        self.close()
+        return False, "; ".join(f"rank {r}: {w[1]}" for r, w in enumerate(res) if not w[0])
+
+    def _release(self):
+        for r in range(self.world):
+            if r != self.rank and self.peers[r]:
+                self.lib.pm_peer_close(self.peers[r])
+                self.peers[r] = None
+        self.lib.pm_peer_destroy(self.base)
+        self.base = None
 
     def close(self):
         if self.base is None:
             return
         torch.cuda.synchronize(self.ops.device)
         dist.barrier(group=self.group)  # nobody still writes into a mailbox that is about to go
-        for r in range(self.world):
-            if r != self.rank and self.peers[r]:
-                self.lib.pm_peer_close(self.peers[r])
-        self.lib.pm_peer_destroy(self.base)
-        self.base = None
+        self._release()
 
     def check(self):
         """Raise if any exchange since creation timed out (synchronous: once per clip, never per exchange)."""
@@ -147,8 +202,15 @@ class FrameParallel:
         self.recorder = None
         if self.world > 1 and ops is not None and hasattr(ops, "lib") and hasattr(ops.lib, "pm_peer_exchange") \
                 and os.environ.get("PANDORA_PEER_MAILBOX", "1") != "0":
-            self.mailbox = PeerMailbox(ops, group, self.rank, self.world)
-            self.calls["mailbox"] = 0
+            mb = PeerMailbox(ops, group, self.rank, self.world)
+            ok, why = mb.commission()  # collective: all ranks keep the mailbox or all fall back
+            if ok:
+                self.mailbox = mb
+                self.calls["mailbox"] = 0
+            else:
+                import warnings
+                warnings.warn("peer mailboxes are not available for this frame group (" + why + "): the GroupNorm / "
+                              "halo exchanges go through torch.distributed point-to-point calls instead")
 
     def _comm(self, fn):
         if self.recorder is None:
@@ -180,14 +242,29 @@ class FrameParallel:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def _mailbox_exchange(self, stats, first=None, last=None):
+        """-> (totals, lo, hi) through the peer mailboxes, or None: no mailbox (then the caller's torch.distributed
+        form runs).  A re-creation for a larger halo frame that fails does so on every rank (PeerUnavailable), so the
+        whole group drops to the torch.distributed form at the same exchange."""
+        if self.mailbox is None:
+            return None
+        try:
+            got = self.mailbox.exchange(stats, first, last)
+        except PeerUnavailable as exc:
+            import warnings
+            warnings.warn(f"peer mailboxes dropped for this frame group ({exc}): torch.distributed point-to-point from here on")
+            self.mailbox = None
+            return None
+        self.calls["mailbox"] += 1
+        return got
+
     # ---- the three in-forward exchanges ---------------------------------------------------------
     def reduce_stats(self, partial, local_count):
         """partial f32 [NI, groups, 2] local {sum, sumsq} -> (all-rank totals, total element count)."""
         self.calls["reduce_stats"] += 1
-        if self.mailbox is not None:
-            self.calls["mailbox"] += 1
-            tot, _, _ = self.mailbox.exchange(partial.contiguous().view(-1))
-            return tot.view_as(partial), float(local_count) * self.world
+        got = self._mailbox_exchange(partial.contiguous().view(-1))
+        if got is not None:
+            return got[0].view_as(partial), float(local_count) * self.world
         tot = partial.contiguous().clone()
         _host_staged_sync(tot, self.group)
         self._comm(lambda: dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group))
@@ -224,10 +301,9 @@ class FrameParallel:
         part = partial.contiguous()
         first = x[:P].contiguous()
         last = x[(self.local_frames - 1) * P:].contiguous()
-        if self.mailbox is not None:  # one kernel launch: peer writes + arrival counters, same rank-order totals
-            self.calls["mailbox"] += 1
-            tot, lo, hi = self.mailbox.exchange(part.view(-1), first, last)
-            return tot.view_as(part), float(local_count) * self.world, lo, hi
+        got = self._mailbox_exchange(part.view(-1), first, last)  # one kernel launch: peer writes + arrival counters,
+        if got is not None:                                        # the same rank-order totals
+            return got[0].view_as(part), float(local_count) * self.world, got[1], got[2]
         _host_staged_sync(x, self.group)
         lo = torch.empty_like(first) if self.rank > 0 else None
         hi = torch.empty_like(first) if self.rank < self.world - 1 else None

@@ -124,6 +124,37 @@ def test_peer_mailbox_exchange_unit(tmp_path, world):
               f"(fine-grained memory: {got['fine_grained']})")
 
 
+def _fallback_worker(rank, world, port, out):
+    _init(rank, world, port)
+    os.environ["PANDORA_PEER_INJECT_FAIL"] = "1"  # rank 1's mailbox "cannot be created"
+    try:
+        import warnings
+        from open_pandora_amd.frame_parallel import FrameParallel
+        from open_pandora_amd.ops_hip import HipOps
+        ops = HipOps(torch.float16, "cuda:0")
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            fp = FrameParallel(16, ops=ops)
+        part = torch.full((1, 32, 2), float(rank + 1), device="cuda")
+        tot, n = fp.reduce_stats(part, 10)
+        torch.save({"mailbox": fp.mailbox is not None, "warned": any("peer mailboxes are not available" in str(x.message) for x in w),
+                    "tot": tot.cpu(), "n": n}, f"{out}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_mailbox_failure_on_one_rank_falls_back_on_every_rank(tmp_path):
+    """A rank that cannot create / map its mailbox must not leave its peers waiting: the go / no-go is collective
+    (PeerMailbox.commission) and the group keeps the torch.distributed form of the exchanges."""
+    out = str(tmp_path / "f.pt")
+    mp.spawn(_fallback_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for r in range(2):
+        got = torch.load(f"{out}.{r}")
+        assert got["mailbox"] is False and got["warned"], (r, got)
+        assert torch.equal(got["tot"], torch.full((1, 32, 2), 3.0)) and got["n"] == 20.0
+
+
 def _build(ops, fp):
     from oracle import golden_recipe as gr
     from open_pandora_amd import synth

@@ -52,10 +52,17 @@ class Prof:
             byts = esz(x) + esz(w) + esz(out)
             return f"ln_gemm M={x.shape[0]} N={w.shape[0]} K={w.shape[1]} a={str(x.dtype)[6:]} o={str(out.dtype)[6:]}" \
                    f"{' act=' + kw['act'] if kw.get('act') else ''}", 2.0 * x.shape[0] * w.shape[0] * w.shape[1], byts
+        fl = 0.0
+        if name in ("attention", "attention_fp8"):  # (F, Nq, C) x (F, Nk, C): QK^T and PV, 2 FLOP per MAC (an MFMA-bound op:
+            q, k = a[0], a[1]                        #  its floor is FLOPs / peak, not its operand bytes)
+            fl = 4.0 * q.shape[0] * q.shape[1] * k.shape[1] * q.shape[2]
+        elif name == "attention_temporal":           # (T, P, C): every pixel attends over the T frames
+            q = a[0]
+            fl = 4.0 * q.shape[0] * q.shape[0] * q.shape[1] * q.shape[2]
         tens = [t for t in list(a) + list(kw.values()) if isinstance(t, torch.Tensor)]
         big = max(tens, key=lambda t: t.numel()) if tens else None
         byts = sum(esz(t) for t in tens) + (esz(out) if isinstance(out, torch.Tensor) else 0)
-        return f"{name} {tuple(big.shape) if big is not None else ''} {str(big.dtype)[6:] if big is not None else ''}", 0.0, byts
+        return f"{name} {tuple(big.shape) if big is not None else ''} {str(big.dtype)[6:] if big is not None else ''}", fl, byts
 
 
 def main():
