@@ -107,7 +107,9 @@ __global__ __launch_bounds__(256) void peer_exchange_kernel(const PeerParams p) 
   }
   // ---- 3. wait for every source (own mailbox: local polls) ----
   if (threadIdx.x == 0) {
-    uint32_t ok = 1;
+    // (fail fast: after one timed-out poll the clip is invalid anyway - pm_peer_status reports it - so later exchanges
+    // of the same mailbox do not wait again: a dead peer costs ONE poll bound per clip, not one per exchange)
+    uint32_t ok = __hip_atomic_load(&ctrl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u;
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     for (int r = 0; r < p.world && ok; ++r) {
       if (r == p.rank) continue;
