@@ -182,12 +182,14 @@ def _segments_supported(fp, dev):
             g.replay()
             if k == 0:
                 with torch.cuda.stream(side):
+                    if fp.backend != "nccl":
+                        side.synchronize()  # (gloo: host-staged, not stream-ordered)
                     dist.all_reduce(buf, group=fp.group)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
     except Exception:  # noqa: BLE001 - any failure means "eager", decided below for every rank at once
         ok = 0
-    flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+    flag = torch.tensor([ok], device=dev if fp.backend == "nccl" else "cpu", dtype=torch.int32)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=fp.group)
     return bool(flag.item())
 
@@ -339,10 +341,12 @@ class DDIMSampler:
             return g(x, t)
 
         fp_u = getattr(unet, "fp", None)
-        # frame shards: HIP graphs of the segments between the in-forward exchanges (RCCL only; PANDORA_SEGMENT_GRAPHS=0
-        # or a failed capture: the eager forward)
+        # frame shards: HIP graphs of the segments between the in-forward exchanges (RCCL; PANDORA_SEGMENT_GRAPHS=0 or a
+        # failed capture: the eager forward; =force: also on gloo, whose exchanges then wait for the stream themselves -
+        # the multi-process rehearsal of the recorder on one GPU, tests/test_peer_gpu.py)
         segmentable = (self.use_graph and getattr(ops, "supports_graphs", False) and isinstance(c, dict) and x.is_cuda
-                       and fp_u is not None and fp_u.backend == "nccl" and not self._seg_failed
+                       and fp_u is not None and not self._seg_failed
+                       and (fp_u.backend == "nccl" or os.environ.get("PANDORA_SEGMENT_GRAPHS") == "force")
                        and os.environ.get("PANDORA_SEGMENT_GRAPHS", "1") != "0")
 
         if segmentable and not self._seg_probed and fp_u.world > 1:

@@ -213,6 +213,16 @@ class FrameParallel:
                               "halo exchanges go through torch.distributed point-to-point calls instead")
 
     def _comm(self, fn):
+        """Issue one torch.distributed exchange - or hand it to the recording _SegmentedForward, which re-issues the same
+        closure at every replay.  gloo stages device tensors through the host without ordering against the stream that
+        produced them: there the closure itself waits for the stream first (inside the closure, so that replays do it too;
+        RCCL is stream-ordered and needs nothing)."""
+        if self.backend != "nccl" and torch.cuda.is_available() and torch.cuda.is_initialized():
+            inner = fn
+
+            def fn():
+                torch.cuda.current_stream().synchronize()
+                inner()
         if self.recorder is None:
             fn()
         else:
@@ -266,7 +276,6 @@ class FrameParallel:
         if got is not None:
             return got[0].view_as(partial), float(local_count) * self.world
         tot = partial.contiguous().clone()
-        _host_staged_sync(tot, self.group)
         self._comm(lambda: dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group))
         return tot, float(local_count) * self.world
 
@@ -275,7 +284,6 @@ class FrameParallel:
         self.calls["exchange_halo"] += 1
         first = t[:P].contiguous()
         last = t[(self.local_frames - 1) * P:].contiguous()
-        _host_staged_sync(t, self.group)
         lo = torch.empty_like(first) if self.rank > 0 else None
         hi = torch.empty_like(first) if self.rank < self.world - 1 else None
         ops = []
@@ -304,7 +312,6 @@ class FrameParallel:
         got = self._mailbox_exchange(part.view(-1), first, last)  # one kernel launch: peer writes + arrival counters,
         if got is not None:                                        # the same rank-order totals
             return got[0].view_as(part), float(local_count) * self.world, got[1], got[2]
-        _host_staged_sync(x, self.group)
         lo = torch.empty_like(first) if self.rank > 0 else None
         hi = torch.empty_like(first) if self.rank < self.world - 1 else None
         parts = [part if r == self.rank else torch.empty_like(part) for r in range(self.world)]
@@ -328,7 +335,6 @@ class FrameParallel:
 
     def _a2a(self, src):
         dst = torch.empty_like(src)
-        _host_staged_sync(src, self.group)
         self._comm(lambda: dist.all_to_all_single(dst, src, group=self.group))
         return dst
 
@@ -355,7 +361,6 @@ class FrameParallel:
         """qkv [F_local, P, 3*inner] (q|k|v): returns k, v views [T, P, inner] over all frames."""
         self.calls["gather_kv"] = self.calls.get("gather_kv", 0) + 1
         kv_local = qkv[..., inner:].contiguous()
-        _host_staged_sync(kv_local, self.group)
         kv_all = torch.empty((self.total_frames,) + tuple(kv_local.shape[1:]), dtype=kv_local.dtype,
                              device=kv_local.device)
         if self.backend == "gloo":

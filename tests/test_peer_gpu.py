@@ -203,6 +203,67 @@ def _unet_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
+def _segmented_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    _init(rank, world, port)
+    try:
+        from oracle import golden_recipe as gr
+        from open_pandora_amd.ddim import DDIMSampler, _SegmentedForward
+        from open_pandora_amd.frame_parallel import FrameParallel
+        from open_pandora_amd.ops_hip import HipOps
+        ops = HipOps(torch.float16, "cuda:0")
+        fp = FrameParallel(16, ops=ops)
+        assert fp.mailbox is not None
+        pm = _build(ops, fp)
+        ins, cond, _ = gr.sampler_inputs(8, 8)
+        dev = lambda d: {k: [v.cuda() for v in lst] for k, lst in d.items()}
+        cond = dev(cond)  # (ONE set of condition tensors: the graph key holds their addresses)
+
+        def run(S=3):
+            smp = DDIMSampler(pm)
+            y, _ = smp.sample(S=S, batch_size=1, shape=(4, 16, 8, 8), conditioning=cond, verbose=False,
+                              unconditional_guidance_scale=1.0, unconditional_conditioning=None, eta=0.0,
+                              fs=torch.tensor([15]).cuda(), timestep_spacing="uniform_trailing", x_T=ins["x_T"].cuda())
+            return y.float().cpu(), smp
+
+        os.environ["PANDORA_SEGMENT_GRAPHS"] = "force"  # (gloo group: the exchanges wait for the stream themselves)
+        seg, smp = run()
+        graphs = [g for g in smp._graphs.values() if isinstance(g, _SegmentedForward)]
+        n_comm = [sum(1 for st in g.steps if not isinstance(st, torch.cuda.CUDAGraph)) for g in graphs]
+        n_steps = [len(g.steps) for g in graphs]
+        calls = dict(fp.calls)
+        os.environ["PANDORA_SEGMENT_GRAPHS"] = "0"
+        eager, smp2 = run()
+        torch.save({"seg": seg, "eager": eager, "n_graphs": len(graphs), "n_comm": n_comm, "n_steps": n_steps,
+                    "failed": smp._seg_failed, "eager_graphs": len(smp2._graphs), "calls": calls,
+                    "epoch": fp.mailbox.check()}, f"{out}.{rank}")
+        fp.mailbox.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_segmented_graph_replay_with_two_ranks(tmp_path):
+    """ADVICE r02: the recorded exchanges of ddim._SegmentedForward had never been REPLAYED with more than one rank.
+    Two processes on the one GPU (gloo group, PANDORA_SEGMENT_GRAPHS=force): the 105 latency-class exchanges of a forward
+    are peer-mailbox launches captured INSIDE the HIP-graph segments, the 34 bulk all-to-alls are the recorded closures
+    between them (32 all-to-alls + 2 K|V gathers); 3 DDIM steps = 1 recording + 2 replays per rank, equal to the eagerly issued sharded run bit for bit."""
+    out = str(tmp_path / "s.pt")
+    mp.spawn(_segmented_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for r in range(2):
+        got = torch.load(f"{out}.{r}")
+        assert not got["failed"] and got["n_graphs"] == 1 and got["eager_graphs"] == 0, got
+        assert got["n_comm"] == [34] and got["n_steps"] == [2 * 34 + 1], got  # graph, all-to-all, graph, ...
+        assert torch.equal(got["seg"], got["eager"]), r
+        assert torch.equal(got["seg"], torch.load(f"{out}.0")["seg"])
+        # the Python forward ran twice in the segmented run (warm-up + recording; the 2 replays do not walk it)
+        c = got["calls"]
+        assert c["mailbox"] == 2 * 105 and c["all_to_all"] + c.get("gather_kv", 0) == 2 * 34, c
+        print(f"\n[parity] segmented replay world=2 rank {r}: 1 recording + 2 replays of [35 graphs | 34 bulk exchanges], "
+              f"105 mailbox exchanges inside the graphs == eager sharded run bit for bit (mailbox epoch {got['epoch']})")
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("world", [2])  # (4 processes time-slice ONE GPU: every exchange then costs a scheduling quantum - the
 #                                          unit test above covers world 4; on 4 GPUs the kernels simply co-run)
