@@ -70,13 +70,26 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const GemmParams p) {
   const int ntiles_total = p.mtiles * p.ntiles;
   const bool geglu = p.act == PM_ACT_GEGLU;
 
-  // ---- work walk: tile t of this workgroup = work item slot + t*G in the XCD-aware supertile order ----
-  const int slot_id = xcd_remap(blockIdx.x, G);
+  // ---- work walk (the ring kernel's): workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its
+  // own L2.  XCD x owns the CONTIGUOUS run [x*per, (x+1)*per) of the supertile-ordered work list and its G/8 workgroups
+  // sweep it in rounds of G/8 consecutive ids, so tiles that run together AND the tiles of consecutive rounds share A / W
+  // panels in that L2.  (Measured neutral against tile t = slot + t*G: the kernel is not bound by where its operands
+  // come from, profiles/r03/gemm256_ab.txt.)
+  const bool xcd_walk = (G & 7) == 0 && ntiles_total > G;
+  const int per_xcd = (ntiles_total + 7) >> 3, gx = G >> 3;
+  const int slot_id = xcd_remap(blockIdx.x, G);  // (fallback walk: round t -> work item t*G + slot_id)
   int my_tiles = 0;
-  if (slot_id < ntiles_total) my_tiles = (ntiles_total - slot_id + G - 1) / G;
+  if (xcd_walk) {
+    const int xcd = blockIdx.x & 7, first = blockIdx.x >> 3;
+    int avail = ntiles_total - xcd * per_xcd;
+    avail = avail < per_xcd ? avail : per_xcd;
+    if (avail > first) my_tiles = (avail - first + gx - 1) / gx;
+  } else if (slot_id < ntiles_total) {
+    my_tiles = (ntiles_total - slot_id + G - 1) / G;
+  }
   auto decode = [&](int t, int& m0, int& n0) {
     constexpr int GM = 8;
-    const int w = slot_id + t * G;
+    const int w = xcd_walk ? (blockIdx.x & 7) * per_xcd + t * gx + (blockIdx.x >> 3) : slot_id + t * G;
     const int grp = w / (GM * p.ntiles);
     const int first_m = grp * GM;
     const int gm = (p.mtiles - first_m < GM) ? p.mtiles - first_m : GM;
