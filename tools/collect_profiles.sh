@@ -36,6 +36,8 @@ timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE $INC --output-format csv -
 python3 tools/pmc_table.py $O/pmc_fetch > $O/pmc_fetch.txt; rm -rf $O/pmc_fetch
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE $INC --output-format csv -d $O/pmc_write -- python3 tools/gemm_probe.py > /dev/null 2>&1
 python3 tools/pmc_table.py $O/pmc_write > $O/pmc_write.txt; rm -rf $O/pmc_write
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE $INC --output-format csv -d $O/pmc_lds -- python3 tools/gemm_probe.py > /dev/null 2>&1
+python3 tools/pmc_table.py $O/pmc_lds > $O/pmc_lds.txt; rm -rf $O/pmc_lds
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE $INC --output-format csv -d $O/pmc_calib -- python3 tools/fetch_calib.py > $O/fetch_calib.txt 2>/dev/null
 python3 tools/pmc_table.py $O/pmc_calib >> $O/fetch_calib.txt; rm -rf $O/pmc_calib
 timeout 600 rocprofv3 --kernel-trace --pmc $PMC_SQ $INC --output-format csv -d $O/pmc_attn -- python3 tools/attn_pmc.py > /dev/null 2>&1

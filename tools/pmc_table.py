@@ -30,6 +30,8 @@ for k, v in d.items():
     if t and "GRBM_GUI_ACTIVE" in avg:
         clk = avg["GRBM_GUI_ACTIVE"] / 8 / t
         line += f"\n   clock ~ {clk / 1e9:.3f} GHz"
+        if "SQ_LDS_IDX_ACTIVE" in avg:  # (LdsUtil of the profiler's derived metrics: LDS cycles in use / (CUs x cycles))
+            line += f"  LDS in use {avg['SQ_LDS_IDX_ACTIVE'] / (t * clk * 256):.3f} of (CUs x cycles)"
         if "SQ_VALU_MFMA_BUSY_CYCLES" in avg:
             line += f"  MFMA pipe busy {avg['SQ_VALU_MFMA_BUSY_CYCLES'] / (t * clk * 1024):.3f} of (SIMDs x cycles)"
     print(line)
