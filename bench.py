@@ -39,7 +39,7 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16, MI355X_MICROARCH.md
 T = 16
 
 KERNELS = {
-    "gemm": "pm_gemm + pm_ln_gemm (dense nn.Linear / 1x1: gemm_kernel<A_DENSE> 2-stage, gemm_ring_kernel<A_DENSE>, split-K reduce; ln_gemm_kernel = LayerNorm + projection at K = 320)",
+    "gemm": "pm_gemm + pm_ln_gemm (dense nn.Linear / 1x1: gemm_kernel<A_DENSE> 2-stage, gemm_ring_kernel<A_DENSE>, gemm_ringw_kernel<A_DENSE> 256x128, gemm256_kernel, split-K reduce; ln_gemm_kernel = LayerNorm + projection at K = 320)",
     "conv3x3": "pm_conv2d_3x3 (gemm_ring_kernel<A_CONV3X3_FAST>; gemm_kernel for f32-operand / strided / upsampling convs)",
     "conv_t3": "pm_conv_temporal_k3 (gemm_kernel / gemm_ring_kernel<A_CONVT3>)",
     "attention": "pm_attention (attn_self_kernel: spatial self-attention; attn_kernel: text+image cross-attention)",
@@ -103,6 +103,7 @@ class TimedOps:
                                          1 if f32_loader else 0, o.ws_bytes)
         name = ("gemm_kernel<A_DENSE, f32 operand> (register-staged)" if f32_loader else
                 "gemm256_kernel (256x256, 8 waves, ping-pong phases)" if ch == 2 else
+                "gemm_ringw_kernel<A_DENSE> (256x128 ring, 4 loader + 4 consumer waves)" if ch == 3 else
                 "gemm_ring_kernel<A_DENSE>" if ch == 1 else "gemm_kernel<A_DENSE> (128x128, 2 LDS stages, 2 workgroups/CU)")
         self._kern(name, r[1], fl)
         return r[0]

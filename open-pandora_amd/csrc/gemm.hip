@@ -755,6 +755,386 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
 #endif
 }
 
+// gemm_ringw: the ring kernel on a 256(M) x 128(N) tile (PANDORA_GEMM_RINGW).  Why: in-kernel stamps of the ring kernel on long
+// K loops (tools/ring_prof.py, 8192^3): the four loader waves spend 645 clocks per K-step ISSUING its 32 DMAs and the consumers
+// wait for them (563 clocks of compute, 207 at the barrier) - and eight loader waves change nothing
+// (profiles/r03/negative_result_ring8_*): the CU's vector-memory path takes ~50 B/clk, a 128x128x64 K-step needs 64 B per
+// MFMA clock.  A 256x128 tile needs 48: four consumer waves of 128x64 (two 64-row accumulator halves, 64 MFMAs and 24
+// ds_read_b128 per K-step), the same four loaders (8 + 4 pieces each), three 48-KiB stages; barrier q publishes stage q.
+template <typename T, int AMODE>
+__global__ __launch_bounds__(512, 1) void gemm_ringw_kernel(const GemmParams p) {
+  static_assert(AMODE != A_CONV3X3, "K tails / nearest-x2 stay on gemm_kernel");
+  constexpr int BMW = 256;                        // tile rows
+  constexpr int STAGE_BYTES = 3 * TILE_BYTES;     // A tile 256 x 64 (32 KiB) | W tile 128 x 64 (16 KiB)
+  constexpr int NSTAGE = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const As = smem;
+  char* const Bs = smem + 2 * TILE_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = gridDim.x;
+  const int nwork = p.mtiles * p.ntiles * p.splits;
+  // Work walk.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2.  When
+  // the grid is a whole number of workgroups per XCD, XCD x owns the CONTIGUOUS id range [x*per, (x+1)*per) and
+  // its G/8 workgroups sweep it in rounds of G/8 consecutive ids: tiles that run together, and the tiles of
+  // consecutive rounds, share A / W panels in that L2 (the round-major walk i*G + slot re-read the panels from
+  // the fabric: FETCH_SIZE 2.2x the algorithmic bytes on the L0 conv, profiles/r01/pmc_traffic.md).
+  const bool xcd_walk = (G & 7) == 0 && nwork > G;
+  const int per_xcd = (nwork + 7) >> 3, gx = G >> 3;
+  const int slot_id = xcd_remap(blockIdx.x, G);  // (fallback: round i -> work item i * G + slot_id)
+  auto work_id = [&](int round) -> int {  // -1: this workgroup has no work in that round (nor later)
+    if (!xcd_walk) {
+      const int w = round * G + slot_id;
+      return w < nwork ? w : -1;
+    }
+    const int xcd = blockIdx.x & 7, local = round * gx + (blockIdx.x >> 3);
+    const int w = xcd * per_xcd + local;
+    return (local < per_xcd && w < nwork) ? w : -1;
+  };
+  const int nk_all = p.K / BK;
+
+  // work item -> (row tile, column tile, K slice), same supertile order as gemm_kernel
+  auto decode = [&](int w, int& mt, int& nt, int& split) {
+    constexpr int GM = 8;
+    split = w % p.splits;
+    const int wg = w / p.splits;
+    const int grp = wg / (GM * p.ntiles);
+    const int first_m = grp * GM;
+    const int gm = (p.mtiles - first_m < GM) ? p.mtiles - first_m : GM;
+    const int rin = wg - grp * GM * p.ntiles;
+    nt = rin / gm;
+    mt = first_m + (rin - nt * gm);
+    if (AMODE == A_CONVT3) {
+      // temporal conv: row tile (frame f, pixel block b) reads the same pixel block of frames f-1, f, f+1.
+      // Enumerate the row tiles pixel-block-major (consecutive ids = consecutive frames of one block), so the
+      // three readers of an input tile run together on one XCD instead of a whole frame of tiles apart
+      const int bpf = p.P / BMW;  // pixel blocks per frame (remap only when tiles do not straddle frames)
+      if (bpf * BMW == p.P && p.mtiles == bpf * p.F) mt = (mt % p.F) * bpf + (mt / p.F);
+    }
+  };
+
+  if (wave >= 4) {
+    // ================= loader waves (see gemm_kernel for the source-side swizzle / scalarised K walk) =====
+    const int lw = __builtin_amdgcn_readfirstlane(wave - 4);  // (scalar: the DMA's LDS base goes to M0 by SALU)
+    const int r8 = lane >> 3;             // row inside an 8-row DMA piece; tile row = 32*j + 8*lw + r8
+    const int lc = (lane & 7) ^ r8;       // logical 16-byte k-chunk this lane fetches ((row & 7) == r8)
+    const char* const Ab = reinterpret_cast<const char*>(p.A);
+    const char* const Wb = reinterpret_cast<const char*>(p.Wt);
+    const char* const zero = reinterpret_cast<const char*>(p.zero);
+    uint32_t b_off[4], a_off[8];
+    int a_y[8], a_x[8];
+    uint32_t inv[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // conv modes: per row, the taps that are zero padding
+    int tap_s = 0, ch_s = 0;
+    int64_t nxt_a = 0, nxt_w = 0;  // fast conv: table entries of the K-step about to be issued
+    int l_round = 0, l_kt = 0, l_kt1 = 0;
+    auto loader_begin = [&]() -> bool {
+      const int w = work_id(l_round);
+      if (w < 0) return false;
+      int mt, nt, split;
+      decode(w, mt, nt, split);
+      const int m0 = mt * BMW, n0 = nt * BN;
+      l_kt = split * p.ktps;
+      l_kt1 = (l_kt + p.ktps < nk_all) ? l_kt + p.ktps : nk_all;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int pr = 32 * j + 8 * lw + r8;  // LDS row of the W tile -> output column (see epilogue_regs)
+        int n = n0 + cperm(pr, p.act == PM_ACT_GEGLU);
+        if (n > p.N - 1) n = p.N - 1;
+        b_off[j] = (uint32_t)(((int64_t)n * p.ldw + lc * 8) * 2);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int m = m0 + 32 * j + 8 * lw + r8;
+        if (m > p.M - 1) m = p.M - 1;
+        if (AMODE == A_DENSE) {
+          a_off[j] = (uint32_t)(((int64_t)m * p.lda + lc * 8) * 2);
+          a_y[j] = a_x[j] = 0;
+        } else if (AMODE == A_CONV3X3_FAST) {
+          const int hw = p.Ho * p.Wo;
+          const int f = m / hw;
+          const int rem = m - f * hw;
+          const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+          a_y[j] = oy * p.stride + 1 - p.pad;
+          a_x[j] = ox * p.stride + 1 - p.pad;
+          a_off[j] = (uint32_t)((((int64_t)f * p.Hin + a_y[j]) * p.Win + a_x[j]) * p.lda * 2 + lc * 16);
+          uint32_t bad = 0;  // bit t: tap t of this row is zero padding
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const int ty = t / 3, tx = t - ty * 3;
+            const bool ok = (unsigned)(a_y[j] + ty - 1) < (unsigned)p.Hv && (unsigned)(a_x[j] + tx - 1) < (unsigned)p.Wv;
+            bad |= ok ? 0u : (1u << t);
+          }
+          inv[j] = bad;
+        } else {
+          const int f = m / p.P;
+          const int pix = m - f * p.P;
+          a_off[j] = (uint32_t)((((int64_t)f * p.P + pix) * p.lda + lc * 8) * 2);
+          a_y[j] = f;
+          a_x[j] = (int)(uint32_t)(((int64_t)pix * p.lda + lc * 8) * 2);  // byte offset inside a halo frame
+          inv[j] = (f == 0 ? 1u : 0u) | (f == p.F - 1 ? 4u : 0u);  // taps reaching frame -1 / frame F
+        }
+      }
+      if (AMODE == A_CONV3X3_FAST) {  // channel-chunk-major walk (see gemm_kernel's load_tile)
+        const int chunk = l_kt / 9;
+        tap_s = l_kt - chunk * 9;
+        ch_s = chunk * BK;
+        nxt_a = p.tap_a[tap_s];
+        nxt_w = p.tap_w[tap_s];
+      } else if (AMODE != A_DENSE) {  // temporal: chunk-major too (frames f-1, f, f+1 per 64-channel chunk), same table
+        const int chunk = l_kt / 3;
+        tap_s = l_kt - chunk * 3;
+        ch_s = chunk * BK;
+        nxt_a = p.tap_a[tap_s];
+        nxt_w = p.tap_w[tap_s];
+      }
+      return true;
+    };
+    auto load_tile = [&](int kt, int buf) {
+      const char* wb = Wb + (int64_t)((AMODE == A_DENSE && p.kwrap && kt * BK >= p.kwrap) ? kt * BK - p.kwrap : kt * BK) * 2;
+      const char* ab = Ab;
+      const char *hlo = nullptr, *hhi = nullptr;
+      int dy = 0, dx = 0;
+      if (AMODE == A_DENSE) {
+        ab = Ab + (int64_t)kt * (BK * 2);
+      } else if (AMODE == A_CONV3X3_FAST) {
+        // per-tap A shift / W offset come from a host-filled table in the kernel arguments (scalar loads by a
+        // uniform index, fetched one K-step ahead at the end of the previous call): the lone loader wave spent
+        // ~150 cycles per K-step on the division by 3 and the 64-bit multiply chains that stood here
+        wb = Wb + nxt_w + (int64_t)ch_s * 2;
+        ab = Ab + nxt_a + (int64_t)ch_s * 2;
+      } else {
+        wb = Wb + nxt_w + (int64_t)ch_s * 2;
+        ab = Ab + nxt_a + (int64_t)ch_s * 2;
+        hlo = p.halo_lo ? reinterpret_cast<const char*>(p.halo_lo) + (int64_t)ch_s * 2 : nullptr;
+        hhi = p.halo_hi ? reinterpret_cast<const char*>(p.halo_hi) + (int64_t)ch_s * 2 : nullptr;
+      }
+      // Conv modes without halo frames: the A tile goes through a buffer descriptor whose base carries the
+      // (uniform) tap shift and channel offset; a lane's offset is its constant centre-tap offset, and a
+      // padding lane gets offset ~0: out of range, for which `buffer_load ... lds` writes ZEROS into LDS
+      // (tools/probes/buffer_lds_oob.hip).  2 VALU per DMA instead of the ~8 of a per-lane 64-bit pointer
+      // select against a zero page (in-kernel stamps: loader issue 950 -> 560 cycles per K-step, which
+      // had made the LOADER the bottleneck of the convs).
+      const bool use_desc = (AMODE != A_DENSE) && p.halo_lo == nullptr && p.halo_hi == nullptr;
+      if (use_desc) {
+        const uint32_t nrec = (uint32_t)((Ab + p.a_bytes) - ab);
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ab, (short)0, (int)nrec, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t voff = a_off[j] | (uint32_t)(-(int)((inv[j] >> tap_s) & 1u));
+          const int dst = buf * STAGE_BYTES + (32 * j + 8 * lw) * 128;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(As + dst), 16, voff, 0, 0, 0);
+          if (j < 4) __builtin_amdgcn_global_load_lds((glb_void*)(wb + b_off[j]), (lds_void*)(Bs + dst), 16, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const char* src;
+          if (AMODE == A_DENSE) {
+            src = ab + a_off[j];
+          } else if (AMODE == A_CONV3X3_FAST) {
+            dy = tap_s / 3;
+            dx = tap_s - dy * 3;
+            const bool ok = (unsigned)(a_y[j] + dy - 1) < (unsigned)p.Hv && (unsigned)(a_x[j] + dx - 1) < (unsigned)p.Wv;
+            src = ok ? ab + a_off[j] : zero;
+          } else {
+            const int sf = a_y[j] + tap_s - 1;
+            src = ab + a_off[j];
+            if (sf < 0) src = hlo ? hlo + (uint32_t)a_x[j] : zero;
+            if (sf >= p.F) src = hhi ? hhi + (uint32_t)a_x[j] : zero;
+          }
+          const int dst = buf * STAGE_BYTES + (32 * j + 8 * lw) * 128;
+          __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(As + dst), 16, 0, 0);
+          if (j < 4) __builtin_amdgcn_global_load_lds((glb_void*)(wb + b_off[j]), (lds_void*)(Bs + dst), 16, 0, 0);
+        }
+      }
+      if (AMODE == A_CONV3X3_FAST) {
+        if (++tap_s == 9) {
+          tap_s = 0;
+          ch_s += BK;
+        }
+        nxt_a = p.tap_a[tap_s];
+        nxt_w = p.tap_w[tap_s];
+      } else if (AMODE != A_DENSE) {
+        if (++tap_s == 3) {
+          tap_s = 0;
+          ch_s += BK;
+        }
+        nxt_a = p.tap_a[tap_s];
+        nxt_w = p.tap_w[tap_s];
+      }
+    };
+    bool l_valid = loader_begin();
+    int l_stage = 0, inflight = 0;
+    auto issue = [&]() {
+      if (!l_valid) return;
+      load_tile(l_kt, l_stage);
+      l_stage = (l_stage + 1 == NSTAGE) ? 0 : l_stage + 1;
+      ++inflight;
+      if (++l_kt == l_kt1) {
+        ++l_round;
+        l_valid = loader_begin();
+      }
+    };
+    issue();
+    issue();
+#ifdef PM_RING_PROF
+    long long t_wait = 0, t_bar = 0, t_issue = 0, t_n = 0;
+#endif
+    // one iteration per K-step q of the consumers.  Barrier q publishes stage q (no pre-read across the barrier here: with
+    // three 48-KiB stages the stage after next is the one the consumers have just left), so everything but the youngest
+    // K-tile (12 DMAs per loader wave) must have landed; it also proves the consumers are done with stage q-1, which the
+    // issue right behind it overwrites with step q+2.
+    while (inflight > 0) {
+#ifdef PM_RING_PROF
+      const long long c0 = clock64();
+#endif
+      if (inflight >= 2)
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef PM_RING_PROF
+      const long long c1 = clock64();
+#endif
+      __builtin_amdgcn_s_barrier();
+#ifdef PM_RING_PROF
+      const long long c2 = clock64();
+#endif
+      issue();
+      --inflight;
+#ifdef PM_RING_PROF
+      const long long c3 = clock64();
+      t_wait += c1 - c0; t_bar += c2 - c1; t_issue += c3 - c2; ++t_n;
+#endif
+    }
+#ifdef PM_RING_PROF
+    if (p.prof && lane == 0) {
+      long long* d = p.prof + ((long long)blockIdx.x * 8 + wave) * 4;
+      d[0] = t_wait; d[1] = t_bar; d[2] = t_issue; d[3] = t_n;
+    }
+#endif
+    return;
+  }
+
+  // ================= consumer waves: wave (wm, wn) owns rows wm*128 .. +128 (two 64-row halves), columns wn*64 .. +64 ==========
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int a_frag = (wm * 128 + fr) * 128, b_frag = (wn * 64 + fr) * 128;
+  const int slot0 = ((fq) ^ (fr & 7)) << 4, slot1 = ((4 + fq) ^ (fr & 7)) << 4;
+  int c_stage = 0;
+#ifdef PM_RING_PROF
+  long long t_cbar = 0, t_comp = 0, t_epi = 0, t_cn = 0;
+#endif
+
+  // fragments of one k-substep: 8 A blocks (two row halves) + 4 W blocks; double-buffered by substep INSIDE a K-step
+  Pack8<T> fa0[8], fb0[4], fa1[8], fb1[4];
+  auto read_frags = [&](Pack8<T>* fa, Pack8<T>* fb, int stg, int slot) {
+    const char* as = As + stg * STAGE_BYTES + a_frag + slot;
+    const char* bs = Bs + stg * STAGE_BYTES + b_frag + slot;
+    // in the order the MFMAs need them (row block i of both halves against all four column blocks, i = 0 first): the first
+    // MFMA waits for three reads, not nine
+    fb[0].u = *reinterpret_cast<const u32x4*>(bs);
+    fa[0].u = *reinterpret_cast<const u32x4*>(as);
+    fa[4].u = *reinterpret_cast<const u32x4*>(as + 4 * 2048);
+#pragma unroll
+    for (int j = 1; j < 4; ++j) fb[j].u = *reinterpret_cast<const u32x4*>(bs + j * 2048);
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+      fa[i].u = *reinterpret_cast<const u32x4*>(as + i * 2048);
+      fa[4 + i].u = *reinterpret_cast<const u32x4*>(as + (4 + i) * 2048);
+    }
+  };
+
+  for (int c_round = 0;; ++c_round) {
+    const int w = work_id(c_round);
+    if (w < 0) break;
+    int mt, nt, split;
+    decode(w, mt, nt, split);
+    const int m0 = mt * BMW, n0 = nt * BN;
+    const int kt0 = split * p.ktps;
+    const int kt1 = (kt0 + p.ktps < nk_all) ? kt0 + p.ktps : nk_all;
+    float bv[4][4];
+    // dense: requested now, needed in the epilogue.  Conv modes (long K loops, a loader with far more scalar state): requested
+    // in front of the epilogue - 16 registers less through the K loop is what keeps their loaders' state out of scratch
+    if constexpr (AMODE == A_DENSE) load_bias_regs(p, bv, n0, wn, fq);
+
+    f32x4 acc0[4][4], acc1[4][4];  // rows m0 + wm*128 + {0, 64} ..
+    const bool res_done = residual_into_acc<T>(p, acc0, m0 + wm * 128, n0, 0, wn, fr, fq);
+    if (res_done) {
+      (void)residual_into_acc<T>(p, acc1, m0 + wm * 128 + 64, n0, 0, wn, fr, fq);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc0[i][j] = acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int kt = kt0; kt < kt1; ++kt) {
+#ifdef PM_RING_PROF
+      const long long c0 = clock64();
+#endif
+      __builtin_amdgcn_s_barrier();  // stage c_stage is in LDS (and the loaders may overwrite the stage we left)
+#ifdef PM_RING_PROF
+      const long long c1 = clock64();
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(fa0, fb0, c_stage, slot0);  // (exposed: three stages leave no landed stage to pre-read across the barrier)
+      __builtin_amdgcn_sched_barrier(0);
+      // second k-substep's 12 reads ride behind the first 12 MFMAs of the first (an MFMA holds the SIMD's issue for 8 of
+      // its 16 cycles: the read goes in the gap), the other 20 cover the last read's latency - the ring kernel's pattern
+      read_frags(fa1, fb1, c_stage, slot1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc0[i][j] = mfma16(fb0[j].v, fa0[i].v, acc0[i][j]);
+          acc1[i][j] = mfma16(fb0[j].v, fa0[4 + i].v, acc1[i][j]);
+        }
+#pragma unroll
+      for (int t = 0; t < 12; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc0[i][j] = mfma16(fb1[j].v, fa1[i].v, acc0[i][j]);
+          acc1[i][j] = mfma16(fb1[j].v, fa1[4 + i].v, acc1[i][j]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      c_stage = (c_stage + 1 == NSTAGE) ? 0 : c_stage + 1;
+#ifdef PM_RING_PROF
+      const long long c2 = clock64();
+      t_cbar += c1 - c0; t_comp += c2 - c1; ++t_cn;
+#endif
+    }
+#ifdef PM_RING_PROF
+    const long long e0 = clock64();
+#endif
+
+    // ---------------- epilogue of this wave's 128x64 block, one 64-row half at a time (the loaders keep streaming) ----
+    {
+      if constexpr (AMODE != A_DENSE) load_bias_regs(p, bv, n0, wn, fq);
+      const int m_eff = m0 + wm * 128;
+      epilogue_regs<T>(p, acc0, bv, m_eff, n0, 0, wn, fr, fq, m_eff >> 6, split, res_done);
+      epilogue_regs<T>(p, acc1, bv, m_eff + 64, n0, 0, wn, fr, fq, (m_eff + 64) >> 6, split, res_done);
+    }
+#ifdef PM_RING_PROF
+    t_epi += clock64() - e0;
+#endif
+  }
+#ifdef PM_RING_PROF
+  if (p.prof && lane == 0) {
+    long long* d = p.prof + ((long long)blockIdx.x * 8 + wave) * 4;
+    d[0] = t_cbar; d[1] = t_comp; d[2] = t_epi; d[3] = t_cn;
+  }
+#endif
+}
+
 // split-K second pass: out = epi(sum_s ws[s]) ; one thread per 4 consecutive columns
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
@@ -886,6 +1266,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const GemmPara
 // device, a process may drive several GPUs).
 constexpr int MAX_DEVICES = 64;
 static int g_ring = 1;  // PANDORA_GEMM_RING: 0 = never, 1 = by prefer_ring(), 2 = always
+static int g_ringw = 1;  // PANDORA_GEMM_RINGW: 0 = never, 1 = by prefer_ringw(), 2 (with PANDORA_GEMM_RING=2) = every unsplit 16-bit call
 static int g_ring_max_work = 0;  // PANDORA_GEMM_RING_MAX_WORK > 0: never use the ring kernel above that many work items
 static int g_num_cus[MAX_DEVICES] = {0};
 static int g_persist_per_cu = 0;    // PANDORA_GEMM_PERSIST: persistent 2-stage workgroups per CU (0 = one work item per workgroup; measured: 2/CU = no gain, 1 or 3/CU 5 % slower)
@@ -906,6 +1287,8 @@ static void init_once() {
   static const bool init = [] {
     const char* m = getenv("PANDORA_SPLITK_MIN_NK");
     if (m) g_split_min_nk = atoi(m);
+    const char* rwe = getenv("PANDORA_GEMM_RINGW");
+    if (rwe) g_ringw = atoi(rwe);
     const char* r = getenv("PANDORA_GEMM_RING");
     if (r) g_ring = atoi(r);
     const char* rw = getenv("PANDORA_GEMM_RING_MAX_WORK");
@@ -1037,6 +1420,38 @@ template <typename T, int AMODE, bool A32> static int launch1(const GemmParams& 
   return check_launch();
 }
 
+constexpr int RINGW_LDS = 3 * 3 * TILE_BYTES;  // three stages of (A 256 x 64 | W 128 x 64)
+// 256-row tiles halve the tile count: only where that does not cost whole-round efficiency (measured per shape in the model:
+// profiles/r03/ringw_ab.txt), unsplit, 16-bit operands, dense and temporal-conv loaders (the 3x3 loader's state does not fit
+// beside the 250-register consumer: its instantiation spills into the DMA issue path)
+static bool prefer_ringw(int amode, const GemmParams& p) {
+  if (amode == A_CONV3X3 || amode == A_CONV3X3_FAST) return false;
+  if (p.splits != 1 || p.K < 8 * BK) return false;  // (K = 320 .. 448: the 256x256 kernel / the 128x128 kernels measure better)
+  const int64_t cu = num_cus();
+  const int64_t n256 = (int64_t)((p.M + 255) / 256) * p.ntiles, n128 = (int64_t)((p.M + BM - 1) / BM) * p.ntiles;
+  const double e256 = (double)n256 / (double)(((n256 + cu - 1) / cu) * cu) * ((double)p.M / (double)(((p.M + 255) / 256) * 256));
+  const double e128 = (double)n128 / (double)(((n128 + cu - 1) / cu) * cu) * ((double)p.M / (double)(((p.M + BM - 1) / BM) * BM));
+  return n256 >= cu * 3 / 4 && e256 >= e128 - 0.06;
+}
+template <typename T, int AMODE> static int launch_ringw(const GemmParams& p, hipStream_t stream) {
+  GemmParams q = p;
+#ifdef PM_RING_PROF
+  q.prof = g_ring_prof;
+#endif
+  q.mtiles = (p.M + 255) / 256;
+  const int64_t nwork = (int64_t)q.mtiles * p.ntiles;
+  const int grid = (int)(nwork < num_cus() ? nwork : num_cus());
+  static bool attr_set[MAX_DEVICES] = {false};
+  const int dev = current_device();
+  if (!attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ringw_kernel<T, AMODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, RINGW_LDS);
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((gemm_ringw_kernel<T, AMODE>), dim3(grid), dim3(512), RINGW_LDS, stream, q);
+  return check_launch();
+}
+
 template <typename T, int AMODE> static int launch_ring(const GemmParams& p, hipStream_t stream) {
   GemmParams q = p;
 #ifdef PM_RING_PROF
@@ -1079,6 +1494,8 @@ static bool prefer_ring(int amode, const GemmParams& p) {
 template <typename T, int AMODE> static int launch(const GemmParams& p, int flags, hipStream_t stream) {
   if (flags & PM_FLAG_A_F32) return launch1<T, AMODE, true>(p, stream);
   if constexpr (AMODE != A_CONV3X3) {
+    if (p.splits == 1 && ((g_ringw == 2 && g_ring == 2) || (g_ringw == 1 && g_ring != 0 && prefer_ringw(AMODE, p))))
+      return launch_ringw<T, AMODE>(p, stream);
     if (g_ring == 2 || (g_ring == 1 && prefer_ring(AMODE, p))) return launch_ring<T, AMODE>(p, stream);
   }
   return launch1<T, AMODE, false>(p, stream);
@@ -1132,7 +1549,8 @@ extern "C" int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, c
   if (K % BK) return PM_E_SHAPE;  // all Linear layers on the path have K % 64 == 0
   plan_split(p, workspace, workspace_bytes);
   if (p.colstats != nullptr && p.splits > 1 && ((p.ldc & 3) || (p.R != nullptr && (p.ldr & 3)))) return PM_E_SHAPE;
-  if (gemm256_wanted(p, flags, num_cus()))  // large MFMA-bound shapes: 256x256 tiles, 8-phase ping-pong (gemm256.hip)
+  // large MFMA-bound shapes: 256x256 tiles, 8-phase ping-pong (gemm256.hip) - where the 256x128 ring kernel is not preferred
+  if (!(g_ringw == 1 && g_ring != 0 && !(flags & PM_FLAG_A_F32) && prefer_ringw(A_DENSE, p)) && gemm256_wanted(p, flags, num_cus()))
     PM_DISPATCH_DTYPE(dtype, T, return (launch_gemm256<T>(p, num_cus(), (hipStream_t)stream)));
   PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_DENSE>(p, flags, (hipStream_t)stream)));
 }
@@ -1229,6 +1647,7 @@ extern "C" int pm_gemm_kernel_choice(int64_t M, int64_t N, int64_t K, int act, i
   p.ntiles = (int)((N + BN - 1) / BN);
   static float dummy_ws;  // (only its non-NULLness matters to plan_split)
   plan_split(p, workspace_bytes ? &dummy_ws : nullptr, workspace_bytes);
+  if (g_ringw == 1 && g_ring != 0 && prefer_ringw(A_DENSE, p)) return 3;  // the 256x128 ring kernel
   if (gemm256_wanted(p, flags, num_cus())) return 2;
   return (g_ring == 2 || (g_ring == 1 && prefer_ring(A_DENSE, p))) ? 1 : 0;
 }

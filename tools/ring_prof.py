@@ -8,15 +8,20 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "gpurun_out", "libpandora_prof.so")
-if "--build" in sys.argv or not os.path.exists(LIB):
+if "--build" in sys.argv or "--rebuild" in sys.argv or not os.path.exists(LIB):
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    src = [os.path.join(ROOT, "open-pandora_amd", "csrc", f) for f in ("gemm.hip", "attn.hip", "norm.hip", "misc.hip")]
+    sys.path.insert(0, ROOT)
+    from open_pandora_amd import build as _b
+    src = [os.path.join(ROOT, "open-pandora_amd", "csrc", f) for f in _b.SOURCES]
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
                     "-DPM_RING_PROF"] + src + ["-o", LIB], check=True)
     if "--build" in sys.argv:
         sys.exit(0)
 os.environ["PANDORA_LIB"] = LIB
 os.environ["PANDORA_GEMM_RING"] = "2"
+os.environ["PANDORA_GEMM256"] = "0"
+if "--ringw" in sys.argv:
+    os.environ["PANDORA_GEMM_RINGW"] = "2"
 import torch  # noqa: E402
 
 sys.path.insert(0, ROOT)
@@ -74,7 +79,7 @@ for F, H, W, C in ((16, 40, 64, 320), (16, 20, 32, 640)):
         assert rc == 0, rc
     report(f"conv3x3 F={F} {H}x{W} C={C}", e0.elapsed_time(e1) * 1e3)
 
-for M, N, K in ((2560, 1280, 3840), (10240, 640, 2560), (40960, 320, 320), (40960, 960, 320), (40960, 320, 1280), (10240, 640, 640)):
+for M, N, K in ((8192, 8192, 8192), (9216, 1280, 5120), (36864, 1920, 640), (2560, 1280, 3840), (10240, 640, 2560), (40960, 320, 320), (40960, 960, 320), (40960, 320, 1280), (10240, 640, 640)):
     a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
     w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16) * 0.02
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
