@@ -223,6 +223,55 @@ def test_conv_temporal(hip_ops_factory, dtype, F, P, C, halo):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_ringw_256x128_tiles(hip_ops_factory, dtype):
+    """gemm_ringw_kernel (the ring kernel on 256x128 tiles, csrc/gemm.hip), selected by the library's own rule
+    (pm_gemm_kernel_choice == 3: unsplit, K >= 512, whole rounds of 256-row tiles): exact-integer product with a ragged last
+    row tile, bias / GEGLU, f32 residual + fused GroupNorm statistics, and the temporal-conv loader incl. halo frames."""
+    ops = hip_ops_factory(dtype)
+    M, N, K = 49000, 128, 512  # 192 row tiles of 256 (the last one ragged: 104 rows) x 1 column tile
+    assert ops.lib.pm_gemm_kernel_choice(M, N, K, 0, 0, ops.ws_bytes) == 3
+    g = torch.Generator().manual_seed(11)
+    a = torch.randint(-3, 4, (M, K), generator=g).to(dtype)
+    w = torch.randint(-3, 4, (N, K), generator=g).to(dtype)
+    w[:, 1::3] *= 0
+    want = a.float() @ w.float().t()
+    assert torch.equal(ops.gemm(a.cuda(), w.cuda()).float().cpu(), want.to(dtype).float())
+    # random operands: bias + 16-bit residual; f32 stream output + f32 residual + statistics; GEGLU
+    a, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=2)
+    bias, res = rnd(N, dtype=torch.float32, seed=3), rnd(M, N, dtype=dtype, seed=4)
+    da, dw, db, dr = dev(a, w, bias, res)
+    assert rel_err(ops.gemm(da, dw, db, dr), REF.gemm(a, w, bias, res, "none")) <= TOL[dtype]
+    res32 = rnd(M, N, dtype=torch.float32, seed=5)
+    got, tot = ops.gemm(da, dw, db, res32.cuda(), stream=True, stats=(1, 32))
+    want32 = a.float() @ w.float().t() + bias + res32
+    assert got.dtype == torch.float32 and rel_err(got, want32) <= 1e-4 + TOL[dtype] * 0.5
+    assert rel_err(tot, TorchOps._with_stats(want32, (1, 32))[1]) <= 2e-3
+    NG = 512  # (value | gate rows: 4 column tiles -> 768 tiles of 256x128 = three whole rounds on 256 CUs)
+    wg, bg = rnd(NG, K, dtype=dtype, scale=K ** -0.5, seed=6), rnd(NG, dtype=torch.float32, seed=7)
+    assert ops.lib.pm_gemm_kernel_choice(M, NG, K, 2, 0, ops.ws_bytes) == 3
+    wgp, bgp = packing.pack_geglu(wg, bg)
+    assert rel_err(ops.gemm(da, wgp.cuda(), bgp.cuda(), act="geglu"), _geglu_ref(a, wg, bg)) <= TOL[dtype]
+    # temporal conv through the same kernel (K = 3 C = 768; 16 frames x 3072 pixels = 192 row tiles), with halo frames
+    F, P, C = 16, 3072, 256
+    x = rnd(F * P, C, dtype=dtype, seed=8)
+    wt = rnd(C, C, 3, 1, 1, dtype=dtype, scale=(3 * C) ** -0.5, seed=9)
+    bt = rnd(C, dtype=torch.float32, seed=10)
+    lo, hi = rnd(P, C, dtype=dtype, seed=12), rnd(P, C, dtype=dtype, seed=13)
+    wp = packing.pack_conv_t3(wt)
+    for halo in (False, True):
+        want_t = REF.conv_t3(x, wp, bt, F, P, halo_lo=lo if halo else None, halo_hi=hi if halo else None)
+        got_t = ops.conv_t3(x.cuda(), wp.cuda(), bt.cuda(), F, P, halo_lo=lo.cuda() if halo else None,
+                            halo_hi=hi.cuda() if halo else None)
+        assert rel_err(got_t, want_t) <= TOL[dtype], halo
+
+
+def _geglu_ref(a, w, b):
+    y = a.float() @ w.float().t() + b
+    n = y.shape[1] // 2
+    return y[:, :n] * torch.nn.functional.gelu(y[:, n:])  # proj -> chunk -> x * gelu(gate)  (attention.py:415-422)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("NI,P,C,silu,eps", [(16, 150, 320, True, 1e-5), (1, 2000, 320, True, 1e-5),
                                              (4, 700, 64, False, 1e-6), (2, 33, 1920, True, 1e-5),
                                              (1, 16 * 40, 2560, False, 1e-6)])
