@@ -755,6 +755,16 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
 #endif
 }
 
+// Entry `i` (wave-uniform, 0..8) of a per-tap table in the kernel arguments, by a select chain over constant offsets: indexed
+// dynamically, hipcc demoted the WHOLE by-value GemmParams of gemm_ringw_kernel's 3x3 instantiation to scratch memory (every
+// p.field became a scratch load - 1403 of them, the loader's DMA issue path included: 3-4x slower than the 128x128 ring).
+__device__ __forceinline__ int64_t tap_entry(const int64_t (&t)[9], int i) {
+  int64_t r = t[0];
+#pragma unroll
+  for (int k = 1; k < 9; ++k) r = (i == k) ? t[k] : r;
+  return r;
+}
+
 // gemm_ringw: the ring kernel on a 256(M) x 128(N) tile (PANDORA_GEMM_RINGW).  Why: in-kernel stamps of the ring kernel on long
 // K loops (tools/ring_prof.py, 8192^3): the four loader waves spend 645 clocks per K-step ISSUING its 32 DMAs and the consumers
 // wait for them (563 clocks of compute, 207 at the barrier) - and eight loader waves change nothing
@@ -829,7 +839,9 @@ __global__ __launch_bounds__(512, 1) void gemm_ringw_kernel(const GemmParams p) 
     int tap_s = 0, ch_s = 0;
     int64_t nxt_a = 0, nxt_w = 0;  // fast conv: table entries of the K-step about to be issued
     int l_round = 0, l_kt = 0, l_kt1 = 0;
-    auto loader_begin = [&]() -> bool {
+    // (always_inline: left to the inliner, the 3x3 instantiation kept loader_begin - 8 rows x 9 taps - as a real function:
+    // its by-reference captures, the kernel's GemmParams among them, then live in scratch memory)
+    auto loader_begin = [&]() __attribute__((always_inline)) -> bool {
       const int w = work_id(l_round);
       if (w < 0) return false;
       int mt, nt, split;
@@ -880,18 +892,18 @@ __global__ __launch_bounds__(512, 1) void gemm_ringw_kernel(const GemmParams p) 
         const int chunk = l_kt / 9;
         tap_s = l_kt - chunk * 9;
         ch_s = chunk * BK;
-        nxt_a = p.tap_a[tap_s];
-        nxt_w = p.tap_w[tap_s];
+        nxt_a = tap_entry(p.tap_a, tap_s);
+        nxt_w = tap_entry(p.tap_w, tap_s);
       } else if (AMODE != A_DENSE) {  // temporal: chunk-major too (frames f-1, f, f+1 per 64-channel chunk), same table
         const int chunk = l_kt / 3;
         tap_s = l_kt - chunk * 3;
         ch_s = chunk * BK;
-        nxt_a = p.tap_a[tap_s];
-        nxt_w = p.tap_w[tap_s];
+        nxt_a = tap_entry(p.tap_a, tap_s);
+        nxt_w = tap_entry(p.tap_w, tap_s);
       }
       return true;
     };
-    auto load_tile = [&](int kt, int buf) {
+    auto load_tile = [&](int kt, int buf) __attribute__((always_inline)) {
       const char* wb = Wb + (int64_t)((AMODE == A_DENSE && p.kwrap && kt * BK >= p.kwrap) ? kt * BK - p.kwrap : kt * BK) * 2;
       const char* ab = Ab;
       const char *hlo = nullptr, *hhi = nullptr;
@@ -954,20 +966,20 @@ __global__ __launch_bounds__(512, 1) void gemm_ringw_kernel(const GemmParams p) 
           tap_s = 0;
           ch_s += BK;
         }
-        nxt_a = p.tap_a[tap_s];
-        nxt_w = p.tap_w[tap_s];
+        nxt_a = tap_entry(p.tap_a, tap_s);
+        nxt_w = tap_entry(p.tap_w, tap_s);
       } else if (AMODE != A_DENSE) {
         if (++tap_s == 3) {
           tap_s = 0;
           ch_s += BK;
         }
-        nxt_a = p.tap_a[tap_s];
-        nxt_w = p.tap_w[tap_s];
+        nxt_a = tap_entry(p.tap_a, tap_s);
+        nxt_w = tap_entry(p.tap_w, tap_s);
       }
     };
     bool l_valid = loader_begin();
     int l_stage = 0, inflight = 0;
-    auto issue = [&]() {
+    auto issue = [&]() __attribute__((always_inline)) {
       if (!l_valid) return;
       load_tile(l_kt, l_stage);
       l_stage = (l_stage + 1 == NSTAGE) ? 0 : l_stage + 1;
@@ -1422,10 +1434,9 @@ template <typename T, int AMODE, bool A32> static int launch1(const GemmParams& 
 
 constexpr int RINGW_LDS = 3 * 3 * TILE_BYTES;  // three stages of (A 256 x 64 | W 128 x 64)
 // 256-row tiles halve the tile count: only where that does not cost whole-round efficiency (measured per shape in the model:
-// profiles/r03/ringw_ab.txt), unsplit, 16-bit operands, dense and temporal-conv loaders (the 3x3 loader's state does not fit
-// beside the 250-register consumer: its instantiation spills into the DMA issue path)
+// profiles/r03/ringw_ab.txt), unsplit, 16-bit operands, the dense / fast 3x3 / temporal loaders
 static bool prefer_ringw(int amode, const GemmParams& p) {
-  if (amode == A_CONV3X3 || amode == A_CONV3X3_FAST) return false;
+  if (amode == A_CONV3X3) return false;  // (general 3x3 mode: K tails / nearest-x2 stay on gemm_kernel)
   if (p.splits != 1 || p.K < 8 * BK) return false;  // (K = 320 .. 448: the 256x256 kernel / the 128x128 kernels measure better)
   const int64_t cu = num_cus();
   const int64_t n256 = (int64_t)((p.M + 255) / 256) * p.ntiles, n128 = (int64_t)((p.M + BM - 1) / BM) * p.ntiles;
@@ -1550,7 +1561,8 @@ extern "C" int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, c
   plan_split(p, workspace, workspace_bytes);
   if (p.colstats != nullptr && p.splits > 1 && ((p.ldc & 3) || (p.R != nullptr && (p.ldr & 3)))) return PM_E_SHAPE;
   // large MFMA-bound shapes: 256x256 tiles, 8-phase ping-pong (gemm256.hip) - where the 256x128 ring kernel is not preferred
-  if (!(g_ringw == 1 && g_ring != 0 && !(flags & PM_FLAG_A_F32) && prefer_ringw(A_DENSE, p)) && gemm256_wanted(p, flags, num_cus()))
+  if (!(g_ringw == 1 && g_ring != 0 && !(flags & PM_FLAG_A_F32) && prefer_ringw(A_DENSE, p)) && !(g_ringw == 2 && g_ring == 2) &&
+      gemm256_wanted(p, flags, num_cus()))
     PM_DISPATCH_DTYPE(dtype, T, return (launch_gemm256<T>(p, num_cus(), (hipStream_t)stream)));
   PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_DENSE>(p, flags, (hipStream_t)stream)));
 }
@@ -1647,8 +1659,9 @@ extern "C" int pm_gemm_kernel_choice(int64_t M, int64_t N, int64_t K, int act, i
   p.ntiles = (int)((N + BN - 1) / BN);
   static float dummy_ws;  // (only its non-NULLness matters to plan_split)
   plan_split(p, workspace_bytes ? &dummy_ws : nullptr, workspace_bytes);
-  if (g_ringw == 1 && g_ring != 0 && prefer_ringw(A_DENSE, p)) return 3;  // the 256x128 ring kernel
-  if (gemm256_wanted(p, flags, num_cus())) return 2;
+  if (p.splits == 1 && ((g_ringw == 2 && g_ring == 2) || (g_ringw == 1 && g_ring != 0 && prefer_ringw(A_DENSE, p))))
+    return 3;  // the 256x128 ring kernel (launch<T, A_DENSE>'s first choice)
+  if (!(g_ringw == 2 && g_ring == 2) && gemm256_wanted(p, flags, num_cus())) return 2;
   return (g_ring == 2 || (g_ring == 1 && prefer_ring(A_DENSE, p))) ? 1 : 0;
 }
 
