@@ -40,6 +40,14 @@ for _ in range(REP):
     ops.ln_gemm(xf, g1, b1, w_qkv)                                 # pm_ln_gemm: LayerNorm + q|k|v, M=40960 N=960 K=320
 for _ in range(REP):
     ops.ln_gemm(xf, g1, b1, w_ff1, z(8 * C), act="geglu")          # pm_ln_gemm: LayerNorm + GEGLU ff1, N=2560
+# the 576x1024 level-1 / level-0 shapes the 256x128 ring kernel takes (gemm_ringw_kernel<A_DENSE> / <A_CONV3X3_FAST>)
+x2 = r(16 * 36 * 64, 640)
+for _ in range(REP):
+    ops.gemm(x2, w1, z(5120), act="geglu")                         # M=36864 N=5120 K=640 geglu
+xl0 = r(16 * 72 * 128, C)
+for _ in range(REP):
+    ops.conv3x3(xl0, wp, z(C), F, 72, 128)                         # M=147456 N=320 K=2880
+del x2, xl0
 xf2 = torch.randn(16 * 72 * 128, C, device="cuda") * 1.5
 for _ in range(REP):
     ops.ln_gemm(xf2, g1, b1, w_ff1, z(8 * C), act="geglu")         # the same at 576x1024: M=147456
