@@ -194,6 +194,15 @@ int pm_layernorm(const void* x, int64_t ldx, const float* gamma, const float* be
 int pm_split16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t M, int64_t K, int with_lo, int dtype,
                void* stream);
 
+/* pm_split16_upsample2x: pm_split16 written through the nearest-neighbour x2 interpolation of Upsample
+ * (openaimodel3d.py:96-108: F.interpolate(scale_factor=(1, 2, 2), mode="nearest") in front of its 3x3 conv): output row
+ * (f, oy, ox) of a 2H x 2W frame = converted input row (f, oy >> 1, ox >> 1).  The conv behind it then runs in the fast
+ * 3x3 mode on the DMA-staged 256x128 / 128x128 ring kernels instead of gathering the upsampled pixels per lane in the
+ * general mode (2-stage kernel, 0.59-0.76 PFLOP/s on these 1.1-TFLOP launches).
+ *   x f32 [F*H*W, K] (ldx % 4 == 0), y `dtype` [F*2H*2W, K or 2K] (ldy % 8 == 0), K % 8 == 0. */
+int pm_split16_upsample2x(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t F, int64_t H, int64_t W, int64_t K,
+                          int with_lo, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * pm_ln_gemm:  C[M, N] = epilogue( LayerNorm(X)[M, K] · W[N, K]^T )  in ONE kernel: the LayerNorm output never
  * exists in HBM.  replaces the pairs norm1 -> attn1.to_q|k|v, norm2 -> attn2.to_q (or to_q|k|v), norm3 ->

@@ -41,6 +41,8 @@ SIGNATURES = {
     "pm_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                              c_int64, c_float, c_int, c_int, c_void_p]),
     "pm_split16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "pm_split16_upsample2x": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
+                                      c_void_p]),
     "pm_ln_gemm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_void_p,
                            c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
     "pm_ln_gemm_supported": (c_int, [c_int64, c_int64, c_int64, c_int]),

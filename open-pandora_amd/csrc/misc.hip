@@ -216,6 +216,58 @@ extern "C" int pm_split16(const float* x, int64_t ldx, void* y, int64_t ldy, int
   return pm::check_launch();
 }
 
+// The same conversion written through a nearest-neighbour x2 upsample: output pixel (f, oy, ox) of a 2H x 2W frame takes
+// input pixel (f, oy >> 1, ox >> 1).  One thread per 8 elements of an OUTPUT row (each input chunk is read four times: L2).
+template <typename T>
+__global__ __launch_bounds__(256) void split16_up2_kernel(const float* __restrict__ x, int64_t ldx, T* __restrict__ y,
+                                                          int64_t ldy, int64_t Mo, int K8, int with_lo, int H, int W) {
+  const int64_t total = Mo * K8;
+  const int Wo = 2 * W, HWo = 4 * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t mo = i / K8;
+    const int c = (int)(i - mo * K8) * 8;
+    const int64_t f = mo / HWo;
+    const int rem = (int)(mo - f * HWo);
+    const int oy = rem / Wo, ox = rem - oy * Wo;
+    const int64_t mi = (f * H + (oy >> 1)) * W + (ox >> 1);
+    const float* xp = x + mi * ldx + c;
+    const pm::f32x4 a = *reinterpret_cast<const pm::f32x4*>(xp);
+    const pm::f32x4 b = *reinterpret_cast<const pm::f32x4*>(xp + 4);
+    pm::Pack8<T> hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hi.e[e] = pm::from_f32<T>(a[e]);
+      hi.e[e + 4] = pm::from_f32<T>(b[e]);
+    }
+    T* yp = y + mo * ldy + c;
+    pm::st_global16(yp, hi.u);
+    if (with_lo) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        lo.e[e] = pm::from_f32<T>(a[e] - pm::to_f32(hi.e[e]));
+        lo.e[e + 4] = pm::from_f32<T>(b[e] - pm::to_f32(hi.e[e + 4]));
+      }
+      pm::st_global16(yp + (int64_t)K8 * 8, lo.u);
+    }
+  }
+}
+
+extern "C" int pm_split16_upsample2x(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t F, int64_t H, int64_t W,
+                                     int64_t K, int with_lo, int dtype, void* stream) {
+  if (!x || !y) return PM_E_NULL;
+  if (F < 1 || H < 1 || W < 1 || H > 16384 || W > 16384 || K < 8 || (K & 7) || (ldx & 3) || ldx < K || (ldy & 7) ||
+      ldy < (with_lo ? 2 * K : K))
+    return PM_E_SHAPE;
+  const int64_t Mo = F * 4 * H * W;
+  const int64_t total = Mo * (K / 8);
+  int64_t nb = (total + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  PM_DISPATCH_DTYPE(dtype, T,
+                    hipLaunchKernelGGL((split16_up2_kernel<T>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x,
+                                       ldx, reinterpret_cast<T*>(y), ldy, Mo, (int)(K / 8), with_lo, (int)H, (int)W));
+  return pm::check_launch();
+}
+
 extern "C" const char* pm_strerror(int code) {
   switch (code) {
     case PM_OK: return "ok";

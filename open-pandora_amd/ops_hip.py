@@ -43,6 +43,7 @@ class HipOps:
         # f32 operands (the residual stream into skip 1x1 convs, Downsample / Upsample convs) are rounded by one
         # pm_split16 pass and run on the DMA-staged 16-bit kernels; "0": the register-staged f32 loaders (A/B)
         self.presplit = os.environ.get("PANDORA_PRESPLIT", "1") != "0"
+        self.upsample_presplit = os.environ.get("PANDORA_UPSAMPLE_PRESPLIT", "1") != "0"  # (A/B: 0 = the gathered general mode)
         # The parity configuration (VERDICT r02 #4a): every GroupNorm / LayerNorm output - the A operand of the convs and
         # projections, whose one 16-bit rounding is 57 % of the end-to-end error^2 (tests/test_error_budget_gpu.py) - is
         # written as [hi | lo] (PM_OUT_HILO) and consumed over 2C channels with the weights walked twice (PM_FLAG_W_WRAP
@@ -193,6 +194,16 @@ class HipOps:
         capi.check(rc, f"pm_split16 M={M} K={K}")
         return y
 
+    def split16_upsample2x(self, x, F, H, W, with_lo=False):
+        """f32 [F*H*W, K] -> 16-bit [F*2H*2W, K or 2K]: pm_split16 through a nearest x2 upsample (pm_split16_upsample2x)."""
+        M, K = x.shape
+        assert x.dtype == torch.float32 and x.stride(1) == 1 and M == F * H * W
+        y = self.empty(4 * M, 2 * K if with_lo else K)
+        rc = self.lib.pm_split16_upsample2x(_ptr(x), x.stride(0), _ptr(y), y.stride(0), F, H, W, K, int(with_lo), self.dt,
+                                            self._stream())
+        capi.check(rc, f"pm_split16_upsample2x F={F} H={H} W={W} K={K}")
+        return y
+
     def _gemm_lo(self, a, w, y, stats):
         """y += (a - round16(a)) @ w^T, in place (y f32); fused statistics, if wanted, come from this final pass."""
         M, K = a.shape
@@ -209,7 +220,14 @@ class HipOps:
                 pad_lo=1, stats=None):
         """x [F*H*W, Cin] -> [F*Ho*Wo, Cout]; wp packed [Cout, 9*Cin]."""
         if x.dtype == torch.float32 and self.presplit and x.shape[1] % 8 == 0:
-            x = self.split16(x, with_lo=self.parity)  # the f32 stream (Downsample / Upsample): rounded once here, then the DMA loaders
+            if upsample and stride == 1 and pad_lo == 1 and self.upsample_presplit and x.shape[1] % 64 == 0:
+                # Upsample.conv (openaimodel3d.py:96-108): the nearest x2 interpolation is written out by the conversion pass
+                # (4x the 16-bit bytes, once) and the conv runs in the FAST 3x3 mode on the DMA-staged ring kernels instead of
+                # gathering the upsampled pixels per lane in the general mode
+                x = self.split16_upsample2x(x, F, H, W, with_lo=self.parity)
+                H, W, upsample = 2 * H, 2 * W, False
+            else:
+                x = self.split16(x, with_lo=self.parity)  # the f32 stream (Downsample / Upsample): rounded once here, then the DMA loaders
             # (pm_split16 moves 8-element chunks: other widths keep the register-staged f32 loader)
         if x.shape[1] * 9 == 2 * wp.shape[1]:
             wp = self._repeat_taps(wp, 9)  # [hi | lo] input: the same weights for both halves of every tap

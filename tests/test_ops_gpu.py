@@ -199,6 +199,33 @@ def test_conv3x3(hip_ops_factory, dtype, F, H, W, Cin, Cout, stride, ups):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("F,H,W,Cin,Cout", [(2, 5, 8, 64, 128), (3, 9, 7, 128, 64)])
+def test_conv3x3_upsample_of_the_f32_stream(hip_ops_factory, monkeypatch, dtype, F, H, W, Cin, Cout):
+    """Upsample.conv on the f32 stream (openaimodel3d.py:96-108): pm_split16_upsample2x writes the nearest x2 interpolation
+    in 16 bit and the conv runs in the fast 3x3 mode; equal to the gathered general mode (PANDORA_UPSAMPLE_PRESPLIT=0) up to
+    the summation order, both within the operand-rounding tolerance of the reference formulation."""
+    ops = hip_ops_factory(dtype)
+    x = rnd(F * H * W, Cin, dtype=torch.float32, scale=2.0, seed=1)
+    w = rnd(Cout, Cin, 3, 3, dtype=dtype, scale=(9 * Cin) ** -0.5, seed=2)
+    bias = rnd(Cout, dtype=torch.float32, seed=3)
+    xi = torch.nn.functional.interpolate(x.to(dtype).float().reshape(F, H, W, Cin).permute(0, 3, 1, 2), scale_factor=2, mode="nearest")
+    want = torch.nn.functional.conv2d(xi, w.float(), bias, padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    wp = packing.pack_conv3x3(w)
+    up = ops.split16_upsample2x(x.cuda(), F, H, W)
+    assert torch.equal(up.float().cpu().reshape(F, 2 * H, 2 * W, Cin).permute(0, 3, 1, 2), xi)  # bit-exact rows
+    both = ops.split16_upsample2x(x.cuda(), F, H, W, with_lo=True).float().cpu()  # [hi | lo]: hi + lo carries x at ~2x the mantissa
+    x_up = torch.nn.functional.interpolate(x.reshape(F, H, W, Cin).permute(0, 3, 1, 2), scale_factor=2, mode="nearest")
+    x_up = x_up.permute(0, 2, 3, 1).reshape(-1, Cin)
+    assert torch.equal(both[:, :Cin], up.float().cpu())
+    assert rel_err(both[:, :Cin] + both[:, Cin:], x_up) < (2e-6 if dtype == torch.float16 else 2e-5)
+    got = ops.conv3x3(x.cuda(), wp.cuda(), bias.cuda(), F, H, W, 1, True, stream=True)
+    monkeypatch.setattr(ops, "upsample_presplit", False)
+    gathered = ops.conv3x3(x.cuda(), wp.cuda(), bias.cuda(), F, H, W, 1, True, stream=True)
+    assert got.shape == (F * 4 * H * W, Cout) and got.dtype == torch.float32
+    assert rel_err(got, want) <= 2e-5 and rel_err(gathered, want) <= 2e-5 and rel_err(got, gathered) <= 2e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("F,P,C,halo", [(16, 40, 64, False), (4, 77, 320, False), (2, 50, 128, True)])
 def test_conv_temporal(hip_ops_factory, dtype, F, P, C, halo):
     ops = hip_ops_factory(dtype)
