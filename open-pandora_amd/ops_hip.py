@@ -217,10 +217,10 @@ class HipOps:
         return self._stats_end(y, col, stats)
 
     def conv3x3(self, x, wp, bias, F, H, W, stride=1, upsample=False, residual=None, out=None, stream=False,
-                pad_lo=1, stats=None):
+                pad_lo=1, stats=None, presplit_upsample=True):
         """x [F*H*W, Cin] -> [F*Ho*Wo, Cout]; wp packed [Cout, 9*Cin]."""
         if x.dtype == torch.float32 and self.presplit and x.shape[1] % 8 == 0:
-            if upsample and stride == 1 and pad_lo == 1 and self.upsample_presplit and x.shape[1] % 64 == 0:
+            if upsample and stride == 1 and pad_lo == 1 and self.upsample_presplit and presplit_upsample and x.shape[1] % 64 == 0:
                 # Upsample.conv (openaimodel3d.py:96-108): the nearest x2 interpolation is written out by the conversion pass
                 # (4x the 16-bit bytes, once) and the conv runs in the FAST 3x3 mode on the DMA-staged ring kernels instead of
                 # gathering the upsampled pixels per lane in the general mode

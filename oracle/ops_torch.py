@@ -87,7 +87,7 @@ class TorchOps:
         return self._with_stats(self._out(y, out, stream), stats)
 
     def conv3x3(self, x, wp, bias, F, H, W, stride=1, upsample=False, residual=None, out=None, stream=False,
-                pad_lo=1, stats=None):
+                pad_lo=1, stats=None, presplit_upsample=True):
         cin, cout = x.shape[1], wp.shape[0]
         xi = self._a(x).reshape(F, H, W, cin).permute(0, 3, 1, 2)
         if upsample:
