@@ -99,6 +99,9 @@ def load(path=None):
         raise PandoraKernelError(
             f"{path} not found: build it with `python open-pandora_amd/build.py` "
             "(there is no CPU or PyTorch fallback for the denoising path)")
+    # (a process that will also use torch on the GPU must have imported torch BEFORE this point: torch bundles its own
+    # libamdhip64.so.7 and this library has to resolve that SONAME to the copy torch runs on - HipOps and
+    # __graft_entry__.build() do; loading the ROCm copy first leaves torch's streams in another runtime instance)
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the export is missing
