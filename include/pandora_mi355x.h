@@ -263,12 +263,9 @@ int pm_attention_generic(const void* q, int64_t q_bs, int64_t q_rs, const void* 
                          int64_t k_rs, int64_t Nk, void* o, int64_t o_bs, int64_t o_rs, int64_t B, int64_t heads,
                          int64_t Nq, int64_t D, float scale, int dtype, void* stream);
 
-/* Diagnostics (tools/attn_bench.py, tools/attn_pmc.py; not used by the product path): overrides which kernel variant
- * pm_attention / pm_attention_fp8 launch for single-segment calls - 0 = automatic (also the initial value, unless the
- * environment variable PANDORA_ATTN_VARIANT is set: read once, on first use), 3 / 5 / 9 = older variants kept for A/B
- * runs, 11 / 12 / 13 = ceiling probes of the production kernel whose OUTPUT IS NOT AN ATTENTION RESULT (no global
- * traffic / no softmax / no LDS reads: csrc/attn.hip).  Process-wide, not thread-safe: measurement runs only. */
-void pm_debug_attn_variant(int variant);
+/* (Diagnostics - kernel-variant overrides, ceiling probes, environment tuning switches - are NOT part of this library:
+ * they exist only in the -DPM_DIAG build, libpandora_mi355x_diag.so, declared in include/pandora_mi355x_diag.h.  This
+ * library reads no environment variable and has no mutable process-wide state.) */
 
 /* ------------------------------------------------------------------------------------------------
  * pm_attention_temporal: self-attention over the frame axis at every pixel (head dim 64).

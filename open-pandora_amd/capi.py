@@ -7,7 +7,11 @@ import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("PANDORA_LIB", os.path.join(HERE, "libpandora_mi355x.so"))  # override: kernel experiments
+DIAG_LIB_PATH = os.path.join(HERE, "libpandora_mi355x_diag.so")  # the -DPM_DIAG build (include/pandora_mi355x_diag.h)
+# PANDORA_DIAG_LIB=1: measurement runs (tools/, env A/Bs) load the diagnostics build in place of the shipped library - the
+# only build that reads the PANDORA_* kernel-tuning switches; PANDORA_LIB: an explicit path (kernel experiments)
+LIB_PATH = os.environ.get("PANDORA_LIB", DIAG_LIB_PATH if os.environ.get("PANDORA_DIAG_LIB") == "1"
+                          else os.path.join(HERE, "libpandora_mi355x.so"))
 
 PM_F16, PM_BF16, PM_F32 = 1, 2, 3
 PM_OUT_HILO = 0x100
@@ -56,7 +60,6 @@ SIGNATURES = {
                                  c_void_p]),
     "pm_attention_generic": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p,
                                      c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int, c_void_p]),
-    "pm_debug_attn_variant": (None, [c_int]),
     "pm_attention_temporal": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                       c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int,
                                       c_void_p]),
@@ -82,7 +85,14 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p]),
 }
 
+# include/pandora_mi355x_diag.h: only the diagnostics build exports these
+DIAG_SIGNATURES = {
+    "pm_debug_attn_variant": (None, [c_int]),
+    "pm_debug_attn_stamps": (None, [c_void_p]),
+}
+
 _lib = None
+_diag = None
 
 
 class PandoraKernelError(RuntimeError):
@@ -108,6 +118,23 @@ def load(path=None):
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    return lib
+
+
+def load_diag():
+    """The diagnostics build (every export of the shipped library + DIAG_SIGNATURES) as a handle of its own, beside the
+    shipped library in the same process.  Measurement code only (tools/, bench.py's ceiling leg, variant tests)."""
+    global _diag
+    if _diag is not None:
+        return _diag
+    if not os.path.exists(DIAG_LIB_PATH):
+        raise PandoraKernelError(f"{DIAG_LIB_PATH} not found: build it with `python open-pandora_amd/build.py --diag`")
+    lib = ctypes.CDLL(DIAG_LIB_PATH)
+    for name, (res, args) in {**SIGNATURES, **DIAG_SIGNATURES}.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _diag = lib
     return lib
 
 

@@ -10,52 +10,9 @@
 //                      cdna guide §3 "accumulator tile as the next MFMA's operand"); V^T fragments
 //                      come from the row-major V tile through ds_read_b64_tr_b16.
 // Two key/value segments (text, image) are normalised independently and summed (attention.py:128-142).
-#include <stdlib.h>
-#include <math.h>
-#include <type_traits>
-#include "common.hpp"
+#include "attn_common.hpp"
 
 namespace pm {
-
-struct AttnParams {
-  const void* q;
-  const void* k[2];
-  const void* v[2];
-  void* o;
-  int64_t q_bs, q_rs, o_bs, o_rs;
-  int64_t k_bs[2], k_rs[2];
-  int Nk[2];
-  float w[2];
-  int nseg;
-  int Nq, heads, nqt;
-  float scale_log2e;
-  int prescaled;  // attn_self_kernel: q already carries scale * log2(e) (scale_log2e == 1)
-};
-
-constexpr int KV_TILE = 64;
-constexpr int KV_TILE_BYTES = KV_TILE * 128;  // 64 keys x 64 dims x 2 B
-
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
-
-// value held by lane ^ 32 (v_permlane32_swap: no LDS round trip)
-__device__ __forceinline__ float other_half(float v) {
-  const unsigned u = __float_as_uint(v);
-  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
-}
-
-template <typename T> __device__ __forceinline__ typename Vec<T>::v8 tr_pair(const char* base, int off0, int off1) {
-  // two transposed 4x16 block reads -> 8 keys of one d column (the 32x32x16 A-operand fragment)
-  union {
-    struct { s16x4 lo, hi; } s;
-    typename Vec<T>::v8 v;
-  } u;
-  u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off0));
-  u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off1));
-  return u.v;
-}
 
 // QB = 32-row query blocks per wave.  QB = 1: 128 query rows per workgroup (short sequences, the
 // two-segment cross-attention).  QB = 2: 256 rows per workgroup - every K / V^T fragment read from LDS
@@ -325,6 +282,14 @@ __global__ __launch_bounds__(256, (QB == 1 && RING == 2) ? 3 : 2) void attn_self
   const int bh = wg / p.nqt;
   const int qt = wg - bh * p.nqt;
   const int b = bh / p.heads, head = bh - b * p.heads;
+
+  unsigned long long t_clk0 = 0, t_real0 = 0;
+  if constexpr (PM_DIAG_BUILD) {
+    if (p.stamps) {
+      t_clk0 = __builtin_amdgcn_s_memtime();
+      t_real0 = __builtin_amdgcn_s_memrealtime();
+    }
+  }
 
   int qrow[QB];
   bool q_valid[QB];
@@ -601,6 +566,13 @@ __global__ __launch_bounds__(256, (QB == 1 && RING == 2) ? 3 : 2) void attn_self
           for (int e = 0; e < 4; ++e) ov.e[e] = from_f32<T>(oacc[qb][db][4 * g + e] * inv);
           *reinterpret_cast<u32x2*>(op + db * 32 + 8 * g + 4 * hh) = ov.u;
         }
+    }
+  }
+  if constexpr (PM_DIAG_BUILD) {
+    if (p.stamps && tid == 0) {  // in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz (diagnostics build only)
+      unsigned long long* st = p.stamps + 2 * (size_t)blockIdx.x;
+      st[0] = __builtin_amdgcn_s_memtime() - t_clk0;
+      st[1] = __builtin_amdgcn_s_memrealtime() - t_real0;
     }
   }
 }
@@ -1100,18 +1072,24 @@ template <typename T> __global__ __launch_bounds__(256) void attn_small_kernel(c
 
 using namespace pm;
 
-// kernel selection override for A/B measurements (tools/attn_bench.py); 0 = automatic.  PANDORA_ATTN_VARIANT is read
-// once, on first use (no static initialiser); pm_debug_attn_variant (declared in the header as a diagnostics entry
-// point) overrides it.
+// Kernel selection override for A/B measurements (tools/attn_bench.py) - ONLY in the -DPM_DIAG build
+// (libpandora_mi355x_diag.so, include/pandora_mi355x_diag.h): the shipped library always runs the production kernels,
+// holds no mutable global and instantiates none of the older variants / ceiling probes.
+#ifdef PM_DIAG
 static int g_attn_variant = -1;
 static int attn_variant() {
   if (g_attn_variant < 0) {
-    const char* e = getenv("PANDORA_ATTN_VARIANT");
+    const char* e = diag_env("PANDORA_ATTN_VARIANT");
     g_attn_variant = e ? atoi(e) : 0;
   }
   return g_attn_variant;
 }
 extern "C" void pm_debug_attn_variant(int v) { g_attn_variant = v < 0 ? 0 : v; }
+static unsigned long long* g_attn_stamps = nullptr;
+extern "C" void pm_debug_attn_stamps(void* buf) { g_attn_stamps = reinterpret_cast<unsigned long long*>(buf); }
+#else
+static constexpr int attn_variant() { return 0; }
+#endif
 
 extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const void* k1,
                             const void* v1, int64_t k1_bs, int64_t k1_rs, int64_t Nk1,
@@ -1146,6 +1124,9 @@ extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const voi
   // LDS fragment reads per MFMA, a 4-stage K/V ring, 2.0 GHz instead of 1.75) lose 1-3 % there and more on
   // short sequences; kept for A/B runs.
   const int variant = attn_variant();
+#ifdef PM_DIAG
+  p.stamps = g_attn_stamps;
+#endif
   const bool qb2 = variant == 3 || variant == 5;
   const int rows = qb2 ? 256 : 128;
   p.nqt = (int)((Nq + rows - 1) / rows);
@@ -1155,6 +1136,8 @@ extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const voi
                     hipLaunchKernelGGL((attn_self_kernel<T, QB_, PIPE_, POST_, RING_>), grid, dim3(256), 0,         \
                                        (hipStream_t)stream, p);                                                    \
                     return check_launch())
+#ifdef PM_DIAG
+  if (variant == 16) return launch_attn_self16(p, dtype, grid, (hipStream_t)stream);  // the 16x16x32-MFMA form (attn16.hip)
   if (variant == 9)  // (kept for A/B runs: the round-1 kernel)
     PM_DISPATCH_DTYPE(dtype, T,
                       hipLaunchKernelGGL((attn_kernel<T, 1, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -1172,6 +1155,7 @@ extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const voi
     PM_ATTN_PROBE(3);
 #undef PM_ATTN_PROBE
   }
+#endif
   PM_ATTN_LAUNCH(1, false, false, 2);
 #undef PM_ATTN_LAUNCH
 }
@@ -1202,14 +1186,23 @@ extern "C" int pm_attention_fp8(const void* q, int64_t q_bs, int64_t q_rs, const
   AttnFp8Params p{};
   p.q8 = pp.q8; p.k8 = pp.k8; p.v8t = pp.v8t; p.o = o; p.o_bs = o_bs; p.o_rs = o_rs;
   p.Nq = (int)Nq; p.Nk = (int)Nk; p.Nq_pad = (int)nq; p.Nk_pad = (int)nk; p.heads = (int)heads;
+#ifdef PM_DIAG
   const bool qb2 = attn_variant() == 2;  // (32 rows per wave measured faster at every N: tools/attn_bench.py 101 / 102)
+#else
+  constexpr bool qb2 = false;
+#endif
   const int rows = qb2 ? 256 : 128;
   p.nqt = (int)((Nq + rows - 1) / rows);
   dim3 grid((unsigned)(p.nqt * B * heads));
   PM_DISPATCH_DTYPE(dtype, T,
                     hipLaunchKernelGGL((attn_fp8_pack_kernel<T>), pgrid, dim3(256), 0, (hipStream_t)stream, pp);
-                    if (qb2) hipLaunchKernelGGL((attn_fp8_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
-                    else hipLaunchKernelGGL((attn_fp8_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);
+                    if constexpr (PM_DIAG_BUILD) {
+                      if (qb2) {
+                        hipLaunchKernelGGL((attn_fp8_kernel<T, PM_DIAG_BUILD ? 2 : 1>), grid, dim3(256), 0, (hipStream_t)stream, p);
+                        return check_launch();
+                      }
+                    }
+                    hipLaunchKernelGGL((attn_fp8_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);
                     return check_launch());
 }
 

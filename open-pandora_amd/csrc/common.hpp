@@ -3,9 +3,24 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/pandora_mi355x.h"
+#ifdef PM_DIAG
+#include "../../include/pandora_mi355x_diag.h"
+#endif
 
 namespace pm {
+
+// Tuning overrides and diagnosis switches exist only in the -DPM_DIAG build (libpandora_mi355x_diag.so, build.py
+// --diag): the SHIPPED library reads no environment variable and carries no mutable process-wide state besides
+// write-once per-device caches (re-entrant, no global mutable state; gradio calls from a worker thread).
+#ifdef PM_DIAG
+inline const char* diag_env(const char* name) { return getenv(name); }
+constexpr bool PM_DIAG_BUILD = true;
+#else
+inline const char* diag_env(const char*) { return nullptr; }
+constexpr bool PM_DIAG_BUILD = false;
+#endif
 
 typedef _Float16 f16;
 typedef __bf16 bf16;

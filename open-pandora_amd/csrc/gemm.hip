@@ -1297,19 +1297,19 @@ static long long* g_ring_prof = nullptr;
 
 static void init_once() {
   static const bool init = [] {
-    const char* m = getenv("PANDORA_SPLITK_MIN_NK");
+    const char* m = diag_env("PANDORA_SPLITK_MIN_NK");
     if (m) g_split_min_nk = atoi(m);
-    const char* rwe = getenv("PANDORA_GEMM_RINGW");
+    const char* rwe = diag_env("PANDORA_GEMM_RINGW");
     if (rwe) g_ringw = atoi(rwe);
-    const char* r = getenv("PANDORA_GEMM_RING");
+    const char* r = diag_env("PANDORA_GEMM_RING");
     if (r) g_ring = atoi(r);
-    const char* rw = getenv("PANDORA_GEMM_RING_MAX_WORK");
+    const char* rw = diag_env("PANDORA_GEMM_RING_MAX_WORK");
     if (rw) g_ring_max_work = atoi(rw);
-    const char* sm = getenv("PANDORA_SPLITK_MODEL");
+    const char* sm = diag_env("PANDORA_SPLITK_MODEL");
     if (sm) g_split_model = atoi(sm);
-    const char* sf = getenv("PANDORA_SPLITK_FORCE");
+    const char* sf = diag_env("PANDORA_SPLITK_FORCE");
     if (sf) g_split_force = atoi(sf);
-    const char* ps = getenv("PANDORA_GEMM_PERSIST");
+    const char* ps = diag_env("PANDORA_GEMM_PERSIST");
     if (ps) g_persist_per_cu = atoi(ps);
     return true;
   }();

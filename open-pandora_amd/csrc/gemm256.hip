@@ -281,9 +281,9 @@ static int g_gemm256 = 1;  // PANDORA_GEMM256: 0 = never, 1 = by gemm256_prefer(
 static int g_gemm256_nodma = 0;  // PANDORA_GEMM256_NODMA=1: diagnosis build of the same phases without DMAs (garbage results)
 static void init256() {
   static const bool once = [] {
-    const char* e = getenv("PANDORA_GEMM256");
+    const char* e = diag_env("PANDORA_GEMM256");
     if (e) g_gemm256 = atoi(e);
-    const char* nd = getenv("PANDORA_GEMM256_NODMA");
+    const char* nd = diag_env("PANDORA_GEMM256_NODMA");
     if (nd) g_gemm256_nodma = atoi(nd);
     return true;
   }();

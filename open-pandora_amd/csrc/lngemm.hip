@@ -370,7 +370,7 @@ extern "C" int pm_ln_gemm(const float* X, int64_t ldx, const float* gamma, const
   p.C = C; p.ldc = ldc; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
   p.bias_mul = (flags & PM_FLAG_BIAS_IS_SCALE) ? 1 : 0;
   p.nsplit = ln_choose_nsplit(M, N, K, act, &p.nbw);
-  const char* force = getenv("PANDORA_LNGEMM_NSPLIT");  // tuning override (kernel choice only, never results)
+  const char* force = diag_env("PANDORA_LNGEMM_NSPLIT");  // tuning override (kernel choice only, never results)
   if (force && atoi(force) > 0 && atoi(force) <= N / 32) {
     p.nsplit = atoi(force);
     p.nbw = (int)((N / 32 + p.nsplit - 1) / p.nsplit);

@@ -187,7 +187,11 @@ extern "C" int pm_peer_create(size_t bytes, void** base, void* handle, int* fine
       return PM_E_LAUNCH;
     }
   }
-  if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return PM_E_LAUNCH;
+  if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(p);
+    return PM_E_LAUNCH;
+  }
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
   memcpy(handle, &h, sizeof(h));
   *base = p;

@@ -77,7 +77,12 @@ class _ForwardGraph:
             torch.cuda.current_stream(dev).wait_stream(other)
             torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side):  # the stream whose workspace the warm-up above sized
+        # thread-local capture mode: under the default (global) mode a HIP call made by ANY other thread of the process
+        # while this capture is open fails AND invalidates the capture - e.g. the event query of a torch.distributed
+        # watchdog thread that is still polling the last collective of a previous (sharded) run, which then takes the
+        # process down from that thread (the r03 abort of tests/test_segmented_gpu.py), or another
+        # gradio worker's allocation.  This capture only needs ITS thread's calls to be capturable.
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):  # (the stream whose workspace the warm-up sized)
             main = torch.cuda.current_stream(dev)
             if two:
                 other.wait_stream(main)  # fork
@@ -94,6 +99,10 @@ class _ForwardGraph:
         self.t.copy_(t)
         self.graph.replay()
         return self.e_c, self.e_u
+
+    def close(self):
+        """Drop the graph and the outputs that live in its private pool (DDIMSampler.close)."""
+        self.graph = self.e_c = self.e_u = None
 
 
 class _SegmentedForward:
@@ -162,32 +171,53 @@ class _SegmentedForward:
                 s()
         return self.out
 
+    def close(self):
+        """Drop the segment graphs, the recorded exchange closures (they hold the exchange buffers, which live in the
+        graphs' pool) and the pool handle - in that order, after the device has drained (DDIMSampler.close)."""
+        self.steps = []
+        self.out = self._g = self._pool = None
+
 
 def _segments_supported(fp, dev):
     """Collective go / no-go for the segmented replay (a per-rank fallback leaves the ranks at different
     points of the exchange sequence).  Every rank of the frame group runs the same tiny rehearsal - capture, RCCL call
-    next to the capture, capture - and the minimum of the outcomes decides for ALL of them."""
+    next to the capture, capture - and the minimum of the outcomes decides for ALL of them.  The sequence of collectives
+    is the same on every path: a rank whose capture raised still issues the rehearsal all-reduce (on a
+    plain buffer) before the flag exchange, so RCCL never pairs collectives of different size / dtype."""
     import torch.distributed as dist
     ok = 1
+    side = _capture_streams(dev)[0]
+    buf = pool = None
+
+    def segment():
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=pool, stream=side, capture_error_mode="thread_local"):
+            buf.add_(1.0)
+        g.replay()
+
     try:
-        side = _capture_streams(dev)[0]
         side.wait_stream(torch.cuda.current_stream(dev))
         pool = torch.cuda.graph_pool_handle()
         with torch.cuda.stream(side):
             buf = torch.zeros(64, device=dev)
-        for k in range(2):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, stream=side, capture_error_mode="thread_local"):
-                buf.add_(1.0)
-            g.replay()
-            if k == 0:
-                with torch.cuda.stream(side):
-                    if fp.backend != "nccl":
-                        side.synchronize()  # (gloo: host-staged, not stream-ordered)
-                    dist.all_reduce(buf, group=fp.group)
+        segment()
+    except Exception:  # noqa: BLE001 - any failure means "eager", decided below for every rank at once
+        ok = 0
+    try:
+        if buf is None:
+            buf = torch.zeros(64, device=dev)
+        with torch.cuda.stream(side):
+            if fp.backend != "nccl":
+                side.synchronize()  # (gloo: host-staged, not stream-ordered)
+            dist.all_reduce(buf, group=fp.group)
+    except Exception:  # noqa: BLE001
+        ok = 0
+    try:
+        if ok:
+            segment()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-    except Exception:  # noqa: BLE001 - any failure means "eager", decided below for every rank at once
+    except Exception:  # noqa: BLE001
         ok = 0
     flag = torch.tensor([ok], device=dev if fp.backend == "nccl" else "cpu", dtype=torch.int32)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=fp.group)
@@ -211,6 +241,22 @@ class DDIMSampler:
         self._seg_failed = False  # the frame group decided against segmented replay (or, at one rank, a capture raised)
         self._seg_probed = False
         self._gen = None  # multi-rank noise generator (see _draw)
+
+    def close(self):
+        """Release every captured graph of this sampler: the device drains, the graphs, the exchange closures recorded
+        between them and their private memory pools go, the device drains again.  Call it before
+        `dist.destroy_process_group()` (and before dropping the op table): the recorded exchanges hold RCCL-registered
+        buffers and the pools hold the activations of a forward (explicit lifetimes instead of whatever
+        order the garbage collector picks at interpreter exit)."""
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+        for g in self._graphs.values():
+            g.close()
+        self._graphs.clear()
+        import gc
+        gc.collect()
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
 
     def _fp(self):
         unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
@@ -336,6 +382,8 @@ class DDIMSampler:
                    getattr(unet, "_pack_epoch", 0))
             g = self._graphs.get(key)
             if g is None:
+                for old in self._graphs.values():
+                    old.close()
                 self._graphs.clear()  # one live graph: its private pool holds a forward's activations
                 g = self._graphs[key] = _ForwardGraph(self.model, x, t, cc, uu, fs, kwargs)
             return g(x, t)
@@ -361,14 +409,19 @@ class DDIMSampler:
         def forward_sharded(cc, slot):
             if segmentable:
                 tensors = [v for lst in cc.values() for v in lst] + ([fs] if torch.is_tensor(fs) else [])
-                key = ("seg", slot, tuple(x.shape), tuple((v.data_ptr(), tuple(v.shape)) for v in tensors),
-                       tuple(sorted(kwargs)), getattr(unet, "_pack_epoch", 0))
+                # (the segments hold the peer mailbox's addresses by value: its generation is part of the key, ADVICE r03;
+                # read again after a recording, whose warm-up forward may have re-created the mailbox for a larger halo)
+                mk = lambda: ("seg", slot, tuple(x.shape), tuple((v.data_ptr(), tuple(v.shape)) for v in tensors),
+                              tuple(sorted(kwargs)), getattr(unet, "_pack_epoch", 0),
+                              getattr(getattr(fp_u, "mailbox", None), "generation", 0))
+                key = mk()
                 g = self._graphs.get(key)
                 if g is None:
                     for k in [k for k in self._graphs if k[0] == "seg" and k[1] == slot]:
-                        del self._graphs[k]
+                        self._graphs.pop(k).close()
                     try:
-                        g = self._graphs[key] = _SegmentedForward(self.model, x, t, cc, fs, kwargs, fp_u)
+                        g = _SegmentedForward(self.model, x, t, cc, fs, kwargs, fp_u)
+                        self._graphs[mk()] = g
                     except Exception as exc:  # e.g. an RCCL build that refuses calls next to a capture
                         if fp_u.world > 1:
                             # peers are somewhere inside the recorded exchange sequence: restarting this rank's forward
@@ -507,7 +560,12 @@ class DDIMSampler:
         if fp is not None:
             img = fp.gather_frames(img)
             if getattr(fp, "mailbox", None) is not None:
-                fp.mailbox.check()  # (once per clip: a timed-out peer exchange invalidates the latent)
+                # once per clip, on every rank: a timed-out peer exchange invalidates the latent EVERYWHERE
+                try:
+                    fp.mailbox.check(collective=True)
+                except Exception:
+                    fp.mailbox = None  # (released group-wide by check: torch.distributed exchanges from here on)
+                    raise
         if precision is not None and isinstance(precision, torch.dtype):
             img = img.to(precision)
         return img, intermediates

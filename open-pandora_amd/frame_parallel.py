@@ -54,6 +54,9 @@ class PeerMailbox:
         self.halo_max = 0
         self.fine_grained = None
         self.exchanges = 0
+        # bumped by every (re-)creation: captured HIP graphs hold the mailbox addresses BY VALUE inside their launch
+        # parameters, so the sampler keys its graphs by this number and re-records after a re-creation
+        self.generation = 0
         self.timeout_s = float(os.environ.get("PANDORA_PEER_TIMEOUT_S", "5"))
 
     def _create(self, halo_bytes):
@@ -67,6 +70,12 @@ class PeerMailbox:
         base, fg = ctypes.c_void_p(), ctypes.c_int()
         handle = ctypes.create_string_buffer(64)
         rc = self.lib.pm_peer_create(nbytes, ctypes.byref(base), handle, ctypes.byref(fg))
+        if rc == 0 and not fg.value and os.environ.get("PANDORA_PEER_ALLOW_COARSE", "0") != "1":
+            # plain (coarse-grained) device memory: peer writes are not guaranteed to become visible inside a RUNNING
+            # kernel there, and the protocol of csrc/peer.hip polls from inside one - a failed commissioning for the
+            # whole group, reported through the handle exchange below like any other creation failure
+            self.lib.pm_peer_destroy(base)
+            rc = -2
         if rc == 0 and os.environ.get("PANDORA_PEER_INJECT_FAIL") == str(self.rank):  # fault injection (tests/test_peer_gpu.py)
             self.lib.pm_peer_destroy(base)
             rc = -1
@@ -77,6 +86,7 @@ class PeerMailbox:
                 self.lib.pm_peer_destroy(base)
             raise PeerUnavailable(f"pm_peer_create failed on rank(s) {[r for r, i in enumerate(infos) if i[0] != 0]}")
         self.base, self.fine_grained = base, bool(fg.value)
+        self.generation += 1
         self.peers = (ctypes.c_void_p * self.world)()
         bad = 0
         for r in range(self.world):
@@ -92,14 +102,14 @@ class PeerMailbox:
             self._release()
             raise PeerUnavailable(f"pm_peer_open failed on rank(s) {[r for r, f in enumerate(flags) if f]}")
 
-    def commission(self):
+    def commission(self, halo_bytes=0):
         """Collective go / no-go at construction: map the mailboxes and run ONE exchange of known values with a short
         timeout.  -> True on every rank, or False on every rank (the group then keeps the torch.distributed form of
         the two exchanges).  A platform where peer writes / system-scope atomics between the group's devices do not
         work shows up here as a timed-out or wrong exchange instead of as a hang in the middle of a clip."""
         ok, why = 1, ""
         try:
-            self._create(0)
+            self._create(int(halo_bytes))  # (sized once for the largest halo frame the caller announces: no re-creation later)
         except PeerUnavailable as exc:  # (raised on every rank)
             return False, str(exc)
         keep, self.timeout_s = self.timeout_s, min(self.timeout_s, 2.0)
@@ -137,14 +147,26 @@ class PeerMailbox:
         dist.barrier(group=self.group)  # nobody still writes into a mailbox that is about to go
         self._release()
 
-    def check(self):
-        """Raise if any exchange since creation timed out (synchronous: once per clip, never per exchange)."""
+    def check(self, collective=False):
+        """Raise if any exchange since creation timed out (synchronous: once per clip, never per exchange).
+        `collective=True` (the sampler, once per clip, on EVERY rank of the group): the error words are MAX-reduced over
+        the group, so a time-out seen by one rank - a peer that was slow rather than dead - raises on all of them at the
+        same point instead of leaving the others to hang in the next clip's collectives; the mailboxes are released
+        group-wide first (the sticky error word and the fail-fast mode go with them) and the group continues on the
+        torch.distributed form of the exchanges."""
         if self.base is None:
             return
         epoch, err = ctypes.c_int(), ctypes.c_int()
         capi.check(self.lib.pm_peer_status(self.base, ctypes.byref(epoch), ctypes.byref(err)), "pm_peer_status")
-        if err.value:
-            raise capi.PandoraKernelError(f"peer mailbox exchange timed out on rank {self.rank} (a peer never arrived "
+        bad = [self.rank] if err.value else []
+        if collective:
+            flags = [None] * self.world
+            dist.all_gather_object(flags, int(err.value != 0), group=self.group)
+            bad = [r for r, f in enumerate(flags) if f]
+            if bad:
+                self.close()
+        if bad:
+            raise capi.PandoraKernelError(f"peer mailbox exchange timed out on rank(s) {bad} (a peer never arrived "
                                           f"within {self.timeout_s} s): the frame-sharded result is invalid")
         return epoch.value
 
@@ -179,9 +201,12 @@ def _host_staged_sync(t, group=None):
 
 
 class FrameParallel:
-    def __init__(self, total_frames, ops=None, group=None, kv_gather=False):
+    def __init__(self, total_frames, ops=None, group=None, kv_gather=False, halo_bytes=None):
         """`kv_gather`: the north-star's literal form of the temporal attention - every rank keeps its frames and
-        all-gathers K|V over the frame axis (`gather_kv`) - instead of the frames <-> pixels re-shard."""
+        all-gathers K|V over the frame axis (`gather_kv`) - instead of the frames <-> pixels re-shard.
+        `halo_bytes`: the largest boundary frame (f32 [H*W, C]: 4*H*W*C bytes at level 0) the peer mailboxes will carry,
+        so that they are sized ONCE at commissioning (default: PANDORA_PEER_HALO_BYTES, else grown - collectively - at
+        the first larger exchange, which invalidates graphs recorded before: the sampler keys them by `generation`)."""
         assert dist.is_initialized(), "init_process_group first (one process per GPU)"
         self.group = group
         self.kv_gather = kv_gather
@@ -203,7 +228,9 @@ class FrameParallel:
         if self.world > 1 and ops is not None and hasattr(ops, "lib") and hasattr(ops.lib, "pm_peer_exchange") \
                 and os.environ.get("PANDORA_PEER_MAILBOX", "1") != "0":
             mb = PeerMailbox(ops, group, self.rank, self.world)
-            ok, why = mb.commission()  # collective: all ranks keep the mailbox or all fall back
+            if halo_bytes is None:
+                halo_bytes = int(os.environ.get("PANDORA_PEER_HALO_BYTES", "0"))
+            ok, why = mb.commission(halo_bytes)  # collective: all ranks keep the mailbox or all fall back
             if ok:
                 self.mailbox = mb
                 self.calls["mailbox"] = 0
@@ -394,7 +421,7 @@ class CFGParallel:
         return (e_mine, e_other) if self.branch == 0 else (e_other, e_mine)
 
 
-def make_hybrid(total_frames, use_cfg=True, kv_gather=False, ops=None):
+def make_hybrid(total_frames, use_cfg=True, kv_gather=False, ops=None, halo_bytes=None):
     """Decompose the world for one clip: with CFG on and an even world size, ranks [0, N/2) take the
     conditional branch and [N/2, N) the unconditional one (CFGParallel pairs r <-> r + N/2); inside a
     branch the N/2 ranks shard the frames (FrameParallel on a sub-group).  Returns (fp, cfgp); either
@@ -403,10 +430,10 @@ def make_hybrid(total_frames, use_cfg=True, kv_gather=False, ops=None):
     if world == 1:
         return None, None
     if not use_cfg or world % 2:  # (use_cfg=False + kv_gather=True at world 8 = the north-star's split: 2 frames per GPU)
-        return FrameParallel(total_frames, ops=ops, kv_gather=kv_gather), None
+        return FrameParallel(total_frames, ops=ops, kv_gather=kv_gather, halo_bytes=halo_bytes), None
     half = world // 2
     groups = [dist.new_group(list(range(b * half, (b + 1) * half))) for b in (0, 1)]
     branch = rank // half
     cfgp = CFGParallel(partner=(rank + half) % world, branch=branch)
-    fp = FrameParallel(total_frames, ops=ops, group=groups[branch], kv_gather=kv_gather) if half > 1 else None
+    fp = FrameParallel(total_frames, ops=ops, group=groups[branch], kv_gather=kv_gather, halo_bytes=halo_bytes) if half > 1 else None
     return fp, cfgp

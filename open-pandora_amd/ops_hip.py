@@ -29,10 +29,12 @@ class HipOps:
     q_prescale = 64 ** -0.5 * 1.4426950408889634
 
     def __init__(self, dtype=torch.bfloat16, device="cuda", workspace_mb=256, fp8_attention=False, fp8_min_tokens=2048,
-                 parity=False):
+                 parity=False, diag=False):
         if dtype not in _DT:
             raise ValueError(f"HipOps supports float16/bfloat16 activations, got {dtype}")
-        self.lib = capi.load()
+        # diag=True: this op table runs on the -DPM_DIAG build of the library (kernel-variant overrides, tuning
+        # switches: include/pandora_mi355x_diag.h) - measurement code and variant tests only
+        self.lib = capi.load_diag() if diag else capi.load()
         # BASELINE configs[4]: the spatial self-attention of the U-Net on pm_attention_fp8 (opt-in: ~2-3e-2 per call)
         self.fp8_attention = bool(fp8_attention)
         self.fp8_min_tokens = int(fp8_min_tokens)  # shorter sequences stay on pm_attention (the packing pass costs more than it saves)

@@ -351,18 +351,22 @@ def gen_frames_small():
     save("frames_small.npz", **out)
 
 
-def gen_frames_full(cases):
+def gen_frames_full(cases, h=40, w=64):
     """Full width (1.44 B U-Net, full AutoencoderKL) at 16x40x64 -> 320x512 frames through the REAL reference:
     (10, 0.0) = BASELINE config 1 (eta 0) and (50, 1.0) = the production schedule with the recipe's shared noise.
-    Hours of CPU: run in the background (`nice`), digests only."""
+    Hours of CPU: run in the background (`nice`), digests only.
+    (h, w) = (72, 128): BASELINE configs[2]'s 576x1024 frames (r04) - the 1024 yaml's base_scale 0.3, the reference's
+    attention called frame by frame (rh.chunk_attention_over_frames: a memory shim, same arithmetic)."""
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count() or 8)))
     t0 = time.time()
-    m = rh.reference_diffusion()
+    big = (h, w) == (72, 128)
+    m = rh.reference_diffusion(base_scale=0.3) if big else rh.reference_diffusion()
     unet = m.model.diffusion_model
     unet.load_state_dict(synth.synth_state_dict(unet, seed=WEIGHT_SEED))
+    if big:
+        rh.chunk_attention_over_frames(unet)
     m.first_stage_model = _reference_first_stage()
     print(f"full model + first stage ready in {time.time() - t0:.0f}s", flush=True)
-    h, w = 40, 64
     ins, cond, uc = _small_setup(320, h, w)
     for S, eta in cases:
         t0 = time.time()
@@ -378,7 +382,7 @@ def gen_frames_full(cases):
         out["frames/per_frame_std"] = frames[0].double().std(dim=(0, 2, 3)).numpy()
         out["wall_seconds"] = np.float64(dt)
         out["threads"] = np.int64(torch.get_num_threads())
-        save(f"frames_full_40x64_s{S}_eta{eta:g}.npz", **out)
+        save(f"frames_full_{h}x{w}_s{S}_eta{eta:g}.npz", **out)
 
 
 if __name__ == "__main__":
@@ -394,11 +398,14 @@ if __name__ == "__main__":
     ap.add_argument("--resampler", action="store_true")
     ap.add_argument("--frames", action="store_true", help="reduced-width sampler -> decode_first_stage frames (seconds)")
     ap.add_argument("--frames-full", default="", help='full-width cases "S:eta,S:eta", e.g. "10:0,50:1" (hours of CPU)')
+    ap.add_argument("--frames-full-72x128", default="", help='the same at 16x72x128 -> 576x1024 frames, e.g. "2:0"')
     a = ap.parse_args()
-    if a.frames or a.frames_full:
+    if a.frames or a.frames_full or a.frames_full_72x128:
         assert rh.available()
         if a.frames:
             gen_frames_small()
+        if a.frames_full_72x128:
+            gen_frames_full([(int(c.split(":")[0]), float(c.split(":")[1])) for c in a.frames_full_72x128.split(",")], 72, 128)
         if a.frames_full:
             gen_frames_full([(int(c.split(":")[0]), float(c.split(":")[1])) for c in a.frames_full.split(",")])
         sys.exit(0)

@@ -45,10 +45,10 @@ def hip_ops_factory():
 
     cache = {}
 
-    def make(dtype):
-        if dtype not in cache:
-            cache[dtype] = HipOps(dtype=dtype, device="cuda:0")
-        return cache[dtype]
+    def make(dtype, diag=False):
+        if (dtype, diag) not in cache:
+            cache[(dtype, diag)] = HipOps(dtype=dtype, device="cuda:0", diag=diag)
+        return cache[(dtype, diag)]
 
     assert torch.cuda.is_available(), "gpu tests need a ROCm device"
     return make

@@ -6,8 +6,8 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "pandora_mi355x.h")).read()
+def declared_symbols(header="pandora_mi355x.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(pm_[a-z0-9_]+)\s*\(", text)))
 
@@ -24,6 +24,25 @@ def test_library_exports_every_declared_symbol():
     loaded = capi.load()
     assert loaded.pm_abi_version() == 1
     assert loaded.pm_strerror(-2).decode().startswith("shape")
+
+
+def test_shipped_library_has_no_diagnostics_and_reads_no_environment():
+    """kernel-variant overrides, probe instantiations and the PANDORA_* tuning switches live in the
+    -DPM_DIAG build only; the shipped library exports none of them and never calls getenv."""
+    import subprocess
+    from open_pandora_amd import build, capi
+    lib = ctypes.CDLL(build.build())
+    diag_syms = declared_symbols("pandora_mi355x_diag.h")
+    assert diag_syms == sorted(capi.DIAG_SIGNATURES) and diag_syms
+    for s in diag_syms:
+        assert not hasattr(lib, s), f"{s} (diagnostics) is exported by the shipped library"
+    und = subprocess.run(["nm", "-D", "--undefined-only", build.LIB], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und, "the shipped library reads the environment"
+    dlib = ctypes.CDLL(build.build(diag=True))
+    for s in declared_symbols() + diag_syms:
+        assert hasattr(dlib, s), f"{s} missing from the diagnostics build"
+    und = subprocess.run(["nm", "-D", "--undefined-only", build.LIB_DIAG], capture_output=True, text=True, check=True).stdout
+    assert "getenv" in und
 
 
 def test_product_refuses_to_run_without_ops():

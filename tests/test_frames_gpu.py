@@ -94,6 +94,40 @@ def test_frames_full_width_320x512(hip_ops_factory, tag, S, eta, dtype):
     torch.cuda.empty_cache()
 
 
+# The north-star's number itself, on FRAMES, no amplification factor: the parity configuration HipOps(parity=True) (norm outputs
+# carried as [hi | lo] 16-bit parts) in f16.  bench.py --parity --dtype f16 puts this configuration's step
+# time on record next to the bf16 production number.
+FRAMES_PARITY_TOL = 1e-3
+
+
+@pytest.mark.parametrize("res,h,w,S", [("320x512", 40, 64, 10), ("576x1024", 72, 128, 2)])
+def test_frames_full_width_parity_mode(res, h, w, S):
+    """Full-width sampler -> first-stage decode in the parity configuration against the REAL reference's frames
+    (DDIMSampler.sample -> decode_first_stage, ddim.py:66 / ddpm3d.py:630-655): BASELINE config 1 (320x512, 10 CFG-4 steps,
+    eta 0) and 576x1024 (configs[2]'s latent, 2 CFG-4 steps: one reference step is ~7 min of CPU at that size)."""
+    path = os.path.join(GOLD, f"frames_full_{h}x{w}_s{S}_eta0.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{os.path.basename(path)} not generated yet (oracle/make_golden.py --frames-full[-72x128])")
+    from open_pandora_amd import factory
+    from open_pandora_amd.ops_hip import HipOps
+    g = np.load(path)
+    ops = HipOps(torch.float16, "cuda:0", parity=True)
+    pm = factory.build_diffusion(res, ops, seed=gr.WEIGHT_SEED)
+    z = _sample(pm, h, w, S, 0.0)
+    del pm
+    torch.cuda.empty_cache()
+    ae = AutoencoderKL()
+    ae.load_state_dict(synth.synth_state_dict(ae, seed=gr.WEIGHT_SEED))
+    frames = ae.bind(ops).decode_first_stage(z)
+    e_z, _, _ = _digest(z, g, "latent")
+    e_f, std, gstd = _digest(frames, g, "frames")
+    print(f"\n[parity] PARITY MODE frames full {res} S={S} eta=0 f16: latent {e_z:.2e} -> frames {e_f:.2e} "
+          f"(std {std:.4f} vs {gstd:.4f})")
+    assert frames.shape == (1, 3, 16, 8 * h, 8 * w) and e_f <= FRAMES_PARITY_TOL
+    del ae
+    torch.cuda.empty_cache()
+
+
 def _oracle_runner():
     """The same driver on the CPU oracle: TorchOps op table + oracle/ae_ref first stage (tests only)."""
     from oracle import ae_ref

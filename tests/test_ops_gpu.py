@@ -651,13 +651,15 @@ def _attn_ref_base2(q, k, v, heads):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("variant", [1, 3, 5])
+@pytest.mark.parametrize("variant", [0, 3, 5, 16])
 def test_attention_stale_max_paths(hip_ops_factory, dtype, variant):
     """attn_self_kernel keeps a STALE running maximum that is only raised when a tile outgrows it by 2^6: force
     every branch (cdna guide rule 26) - a raise in a fast (unmasked, not first) tile, twice for the same row; a
     raise in the last fast tile; rows whose scores stay far BELOW the first tile's maximum; a ragged masked
-    last tile; rows that never raise - in all three kernel variants (32 / 64 rows per wave, pipelined P.V)."""
-    ops = hip_ops_factory(dtype)
+    last tile; rows that never raise - in all kernel variants (32 / 64 rows per wave, pipelined P.V; 16 = the 16x16x32-MFMA
+    form, csrc/attn16.hip)."""
+    # (variant 0 = the shipped library; the other variants exist only in the diagnostics build, include/pandora_mi355x_diag.h)
+    ops = hip_ops_factory(dtype) if variant == 0 else hip_ops_factory(dtype, diag=True)
     B, heads = 2, 3
     C = heads * 64
     try:
@@ -672,13 +674,15 @@ def test_attention_stale_max_paths(hip_ops_factory, dtype, variant):
             k[0, N - 1] = 4 * q[0, 77]  # last key of the clip (masked tile when N = 450)
             q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
             want = REF.attention(q, k, v, heads)
-            ops.lib.pm_debug_attn_variant(variant)
+            if variant:
+                ops.lib.pm_debug_attn_variant(variant)
             got = ops.attention(q.cuda(), k.cuda(), v.cuda(), heads)
             assert rel_err(got, want) <= TOL[dtype], (N, variant)
             for (b, i) in ((0, 5), (1, 100), (1, 300), (0, 77), (0, 6)):  # the forced rows one by one
                 assert rel_err(got[b, i], want[b, i]) <= 2 * TOL[dtype], (N, variant, b, i)
     finally:
-        ops.lib.pm_debug_attn_variant(0)
+        if variant:
+            ops.lib.pm_debug_attn_variant(0)
 
 
 # e4m3 operands (3 mantissa bits) for q, k, v AND the probabilities; an exact-arithmetic emulation of those four

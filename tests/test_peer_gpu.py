@@ -79,7 +79,7 @@ def _unit_worker(rank, world, port, out):
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=side):
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
             t1, lo1, hi1 = mb.exchange(s_in, f_in, l_in)
             t2, _, _ = mb.exchange(t1 * 0.5)  # a dependent, statistics-only exchange in the same graph
             t3, lo3, hi3 = mb.exchange(s_in + 1.0, l_in, f_in)

@@ -1,26 +1,34 @@
 """GPU, one rank on RCCL: the frame-sharded forward replayed as [HIP graph, exchange, HIP graph, ...]
 (ddim._SegmentedForward) gives the eager frame-sharded result bit for bit and the unsharded result to rounding;
 the exchanges (all-reduce, all-to-all) are real RCCL calls issued between the graphs.  (More than one rank
-needs more than one GPU: the multi-rank equality of the same host code is tests/test_frame_parallel_cpu.py.)"""
+needs more than one GPU: the multi-rank equality of the same host code is tests/test_frame_parallel_cpu.py.)
+
+Every test that creates a process group runs in a SPAWNED CHILD: a native abort inside RCCL / the HIP
+runtime is then a failed assertion that carries the child's stderr (faulthandler + C++ stack traces enabled there),
+never the death of the pytest session."""
 import os
 import socket
+import sys
 
 import pytest
 import torch
-import torch.distributed as dist
-
-from oracle import golden_recipe as gr
-from open_pandora_amd import synth
-from open_pandora_amd.ddim import DDIMSampler, _SegmentedForward
-from open_pandora_amd.ddpm import LatentVisualDiffusion
-from open_pandora_amd.frame_parallel import FrameParallel
-from open_pandora_amd.unet import UNetModel
-from test_oracle_golden import RH_KW
+import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _build(ops, fp):
+    from oracle import golden_recipe as gr
+    from open_pandora_amd import synth
+    from open_pandora_amd.ddpm import LatentVisualDiffusion
+    from open_pandora_amd.unet import UNetModel
+    from test_oracle_golden import RH_KW
     m = UNetModel(**dict(RH_KW, model_channels=64)).eval()
     m.load_state_dict(synth.synth_state_dict(m, seed=gr.WEIGHT_SEED))
     m.bind(ops, fp)
@@ -28,6 +36,8 @@ def _build(ops, fp):
 
 
 def _sample(pm, S=3, eta=0.0):
+    from oracle import golden_recipe as gr
+    from open_pandora_amd.ddim import DDIMSampler
     ins, cond, uc = gr.sampler_inputs(8, 8)
     dev = lambda d: {k: [v.cuda() for v in lst] for k, lst in d.items()}
     ns = gr.noises(ins["x_T"].shape, S)
@@ -39,35 +49,65 @@ def _sample(pm, S=3, eta=0.0):
     return y.float().cpu(), smp
 
 
-def test_segmented_graph_replay_of_frame_sharded_forward(hip_ops_factory, monkeypatch):
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _rccl_worker(rank, port, out, kv_gather):
+    import faulthandler
+    faulthandler.enable(all_threads=True)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TORCH_SHOW_CPP_STACKTRACES="1")
+    import torch.distributed as dist
+    from open_pandora_amd.ddim import _SegmentedForward
+    from open_pandora_amd.frame_parallel import FrameParallel
+    from open_pandora_amd.ops_hip import HipOps
+    torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    res = {}
     try:
-        ops = hip_ops_factory(torch.float16)
-        fp = FrameParallel(16)
-        assert fp.backend == "nccl" and fp.world == 1
+        ops = HipOps(torch.float16, "cuda:0")
+        fp = FrameParallel(16, kv_gather=kv_gather)
+        res["backend"], res["world"] = fp.backend, fp.world
+        probe = torch.ones(4, device="cuda")
+        dist.all_reduce(probe)
+        res["rccl_ranks_seen"] = int(probe[0].item())  # (a real communicator answered)
         pm = _build(ops, fp)
         seg, smp = _sample(pm)
         graphs = [g for g in smp._graphs.values() if isinstance(g, _SegmentedForward)]
-        assert len(graphs) == 2 and not smp._seg_failed  # the cond and the uncond forward
-        n_comm = sum(1 for st in graphs[0].steps if not isinstance(st, torch.cuda.CUDAGraph))
-        # at one rank the temporal convs have no neighbour to exchange with: 17 all-reduces + 34 all-to-alls remain
-        assert n_comm == 17 + 34 and len(graphs[0].steps) == 2 * n_comm + 1
-        calls = dict(fp.calls)
-        monkeypatch.setenv("PANDORA_SEGMENT_GRAPHS", "0")
+        res["n_graphs"], res["seg_failed"] = len(graphs), smp._seg_failed
+        res["n_comm"] = sum(1 for st in graphs[0].steps if not isinstance(st, torch.cuda.CUDAGraph))
+        res["n_steps"] = len(graphs[0].steps)
+        res["calls_seg"] = dict(fp.calls)
+        smp.close()  # graphs + their pool go BEFORE anything else touches the process group
+        os.environ["PANDORA_SEGMENT_GRAPHS"] = "0"
         eager, smp2 = _sample(pm)
-        assert not smp2._graphs
-        assert torch.equal(seg, eager)
-        # replays re-issue the recorded exchanges without walking the Python forward: the counters only see the
-        # warm-up + recording passes of the first run (2 branches x 2 passes), the eager run every forward
-        assert calls["reduce_stats"] == 17 * 2 * 2 and fp.calls["reduce_stats"] == calls["reduce_stats"] + 17 * 2 * 3
-        # (the unsharded comparison run with the SAME Upsample form as the sharded forward - frame shards keep the gathered
-        # conv, DESIGN.md section 6 - so that the two differ by the order of the statistics sums only)
-        monkeypatch.setattr(ops, "upsample_presplit", False)
-        plain, _ = _sample(_build(ops, None))
-        assert ((seg - plain).norm() / plain.norm()).item() < 2e-3
+        res["eager_graphs"] = len(smp2._graphs)
+        res["calls_eager"] = dict(fp.calls)
+        plain, smp3 = _sample(_build(ops, None))
+        smp3.close()
+        res.update(seg=seg, eager=eager, plain=plain)
+        torch.cuda.synchronize()
+        torch.save(res, out)
     finally:
+        torch.cuda.synchronize()
         dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("kv_gather", [False, True], ids=["reshard", "kv_gather"])
+def test_segmented_graph_replay_of_frame_sharded_forward(tmp_path, kv_gather):
+    out = str(tmp_path / "seg.pt")
+    mp.spawn(_rccl_worker, args=(_free_port(), out, kv_gather), nprocs=1, join=True)
+    got = torch.load(out)
+    assert got["backend"] == "nccl" and got["world"] == 1 and got["rccl_ranks_seen"] == 1
+    assert got["n_graphs"] == 2 and not got["seg_failed"]  # the cond and the uncond forward
+    # at one rank the temporal convs have no neighbour to exchange with: 17 all-reduces + 34 bulk exchanges remain
+    # (reshard: 34 all-to-alls; kv_gather, the north-star's literal split: one K|V all-gather per temporal attention)
+    assert got["n_comm"] == 17 + 34 and got["n_steps"] == 2 * got["n_comm"] + 1, got
+    assert got["eager_graphs"] == 0
+    assert torch.equal(got["seg"], got["eager"])
+    # replays re-issue the recorded exchanges without walking the Python forward: the counters only see the
+    # warm-up + recording passes of the first run (2 branches x 2 passes), the eager run every forward
+    cs, ce = got["calls_seg"], got["calls_eager"]
+    assert cs["reduce_stats"] == 17 * 2 * 2 and ce["reduce_stats"] == cs["reduce_stats"] + 17 * 2 * 3
+    err = ((got["seg"] - got["plain"]).norm() / got["plain"].norm()).item()
+    print(f"\n[parity] segmented replay over RCCL (1 rank, {'K|V all-gather' if kv_gather else 'frames<->pixels re-shard'}): "
+          f"== eager sharded run bit for bit; vs unsharded {err:.2e}; {got['n_comm']} RCCL calls between {got['n_comm'] + 1} graphs")
+    assert err < 2e-3

@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--variants", default="9,1,3,5,101")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
-    ops = HipOps(dt, "cuda:0")
+    ops = HipOps(dt, "cuda:0", diag=True)  # (variant overrides: the diagnostics build)
     # 101 / 102: pm_attention_fp8 (block-scaled e4m3 MFMA) with 32 / 64 query rows per wave
     variants = [int(v) for v in a.variants.split(",")]
     F = 16

@@ -9,7 +9,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from open_pandora_amd.ops_hip import HipOps  # noqa: E402
 
-ops = HipOps(torch.bfloat16, "cuda:0")
+ops = HipOps(torch.bfloat16, "cuda:0", diag=True)  # (variant overrides: the diagnostics build)
 N, heads, F = (int(sys.argv[1]) if len(sys.argv) > 1 else 9216), 5, 16
 C = heads * 64
 qkv = torch.randn(F, N, 3 * C, device="cuda", dtype=torch.bfloat16)
