@@ -58,7 +58,9 @@ class _ForwardGraph:
     levels) and each with a ramp and a tail; a second, independent chain fills those holes.
     (PANDORA_CFG_STREAMS=0: one stream, the two forwards in sequence.)"""
 
-    def __init__(self, model, x, t, c, uc, fs, kwargs):
+    def __init__(self, model, x, t, c, uc, fs, kwargs, extra=()):
+        """`extra`: further condition sets whose forwards join the graph (the multi-condition sampler's third,
+        image-only branch, ddim_multiplecond.py:232): captured on the main stream behind the conditional forward."""
         self.x = x.clone()
         self.t = t.clone()
         dev = x.device
@@ -89,6 +91,7 @@ class _ForwardGraph:
                 with torch.cuda.stream(other):
                     self.e_u = model.apply_model(self.x, self.t, uc, fs=fs, **kwargs)
             self.e_c = model.apply_model(self.x, self.t, c, fs=fs, **kwargs)
+            self.e_x = [model.apply_model(self.x, self.t, cx, fs=fs, **kwargs) for cx in extra]
             if two:
                 main.wait_stream(other)  # join
             else:
@@ -103,6 +106,7 @@ class _ForwardGraph:
     def close(self):
         """Drop the graph and the outputs that live in its private pool (DDIMSampler.close)."""
         self.graph = self.e_c = self.e_u = None
+        self.e_x = []
 
 
 class _SegmentedForward:
@@ -207,9 +211,11 @@ def _segments_supported(fp, dev):
         if buf is None:
             buf = torch.zeros(64, device=dev)
         with torch.cuda.stream(side):
-            if fp.backend != "nccl":
-                side.synchronize()  # (gloo: host-staged, not stream-ordered)
-            dist.all_reduce(buf, group=fp.group)
+            rec, fp.recorder = fp.recorder, None
+            try:  # (through FrameParallel._comm: RCCL calls never run on a stream that captures, see there)
+                fp._comm(lambda: dist.all_reduce(buf, group=fp.group))
+            finally:
+                fp.recorder = rec
     except Exception:  # noqa: BLE001
         ok = 0
     try:
@@ -225,6 +231,8 @@ def _segments_supported(fp, dev):
 
 
 class DDIMSampler:
+    multicond = False  # DDIMSamplerMultiCond: three forwards per step (text + image guidance, ddim_multiplecond.py:214-234)
+
     def __init__(self, model, schedule="linear", use_graph=None, cfg_parallel=None, ops=None, **kwargs):
         """`ops`: the op table for the fused update kernel; default = the one bound to model's U-Net.  Pass it
         explicitly to run this sampler around a model whose U-Net is not ours (e.g. the reference's own
@@ -358,7 +366,7 @@ class DDIMSampler:
     @torch.no_grad()
     def p_sample_ddim(self, x, c, t, index, temperature=1.0, unconditional_guidance_scale=1.0,
                       unconditional_conditioning=None, fs=None, noise=None, want_x0=True, step=None,
-                      guidance_rescale=0.0, **kwargs):
+                      guidance_rescale=0.0, cfg_img=None, unconditional_conditioning_img_nonetext=None, **kwargs):
         """One denoising step (ddim.py:218-290): two U-Net forwards when CFG is on, then the fused
         update kernel.  `t` is the (b,) long tensor of the current DDPM timestep, `index` its position
         in the DDIM schedule.  `noise` (f32, x-shaped) overrides the device RNG draw."""
@@ -372,10 +380,21 @@ class DDIMSampler:
                      and getattr(unet, "fp", None) is None and x.is_cuda)
         pair = self.cfg_parallel is not None and use_cfg  # this rank runs ONE branch, then one exchange
 
-        def replay(cc, uu):
+        uc_img = unconditional_conditioning_img_nonetext if (self.multicond and use_cfg) else None
+        if self.multicond and use_cfg:
+            if uc_img is None:
+                # (the reference calls apply_model(x, t, None) here and fails inside the U-Net, ddim_multiplecond.py:232;
+                # model.py:737-743 only builds this condition set when cfg_img != 1.0)
+                raise ValueError("the multi-condition sampler needs `unconditional_conditioning_img_nonetext` (image tokens + "
+                                 "empty text, model.py:737-743) whenever unconditional_guidance_scale != 1")
+            if self._multi_rank():
+                raise NotImplementedError("the multi-condition sampler runs on one GPU (three forwards per step)")
+
+        def replay(cc, uu, extra=()):
             if hasattr(unet, "packed") and getattr(unet, "ops", None) is not None:
                 unet.packed()  # re-packs (and moves the pack epoch in the key below) after an in-place weight edit
-            tensors = [v for d in (cc, uu or {}) for lst in d.values() for v in lst] + ([fs] if torch.is_tensor(fs) else [])
+            tensors = ([v for d in (cc, uu or {}) + tuple(extra) for lst in d.values() for v in lst]
+                       + ([fs] if torch.is_tensor(fs) else []))
             # (a weight reload / .to() re-packs the kernel-side weights: the captured graph holds raw pointers to the
             # old ones, so the U-Net's pack epoch is part of the key)
             key = (tuple(x.shape), tuple((v.data_ptr(), tuple(v.shape)) for v in tensors), tuple(sorted(kwargs)),
@@ -385,8 +404,8 @@ class DDIMSampler:
                 for old in self._graphs.values():
                     old.close()
                 self._graphs.clear()  # one live graph: its private pool holds a forward's activations
-                g = self._graphs[key] = _ForwardGraph(self.model, x, t, cc, uu, fs, kwargs)
-            return g(x, t)
+                g = self._graphs[key] = _ForwardGraph(self.model, x, t, cc, uu, fs, kwargs, extra)
+            return g(x, t) + tuple(g.e_x)
 
         fp_u = getattr(unet, "fp", None)
         # frame shards: HIP graphs of the segments between the in-forward exchanges (RCCL; PANDORA_SEGMENT_GRAPHS=0 or a
@@ -446,8 +465,13 @@ class DDIMSampler:
             else:
                 e_mine = replay(mine, None)[0] if graphable else self.model.apply_model(x, t, mine, fs=fs, **kwargs)
             e_c, e_u = self.cfg_parallel.exchange(e_mine)
+        elif uc_img is not None:  # multi-condition: conditional, unconditional and image-only ("" text) forwards
+            if graphable:
+                e_c, e_u, e_ui = replay(c, uc, (uc_img,))
+            else:
+                e_c, e_u, e_ui = (self.model.apply_model(x, t, cc, fs=fs, **kwargs) for cc in (c, uc, uc_img))
         elif graphable and self.cfg_parallel is None:
-            e_c, e_u = replay(c, uc)
+            e_c, e_u = replay(c, uc)[:2]
         elif fp_u is not None:
             e_c = forward_sharded(c, 0)
             e_u = forward_sharded(uc, 1) if use_cfg else None
@@ -455,7 +479,17 @@ class DDIMSampler:
             e_c = self.model.apply_model(x, t, c, fs=fs, **kwargs)
             e_u = self.model.apply_model(x, t, uc, fs=fs, **kwargs) if use_cfg else None
         cfg_scale = float(unconditional_guidance_scale)
-        if use_cfg and guidance_rescale > 0.0:
+        if uc_img is not None:
+            # ddim_multiplecond.py:233-236: text guidance on top of image guidance, then (optionally) rescale_noise_cfg against
+            # the conditional output; the fused update kernel takes the finished model output (e_u = None, cfg = 1)
+            ci = cfg_scale if cfg_img is None else float(cfg_img)
+            v = e_u + ci * (e_ui - e_u) + cfg_scale * (e_c - e_ui)
+            if guidance_rescale > 0.0:
+                dims = list(range(1, e_c.dim()))
+                resc = v * (e_c.std(dim=dims, keepdim=True) / v.std(dim=dims, keepdim=True))
+                v = guidance_rescale * resc + (1.0 - guidance_rescale) * v
+            e_c, e_u, cfg_scale = v, None, 1.0
+        elif use_cfg and guidance_rescale > 0.0:
             # rescale_noise_cfg (utils_diffusion.py:147-158, ddim.py:240-241): match the guided output's
             # per-sample std to the conditional one, blended by guidance_rescale.  A reduction over the
             # whole (655k-element) model output: plain torch on the f32 outputs, then the fused update
@@ -545,6 +579,9 @@ class DDIMSampler:
                 img_orig = x0 if clean_cond else self.model.q_sample(x0, ts.cpu()).to(device)
                 img = (img_orig * mask + (1.0 - mask) * img).float().contiguous()
             noise = noise_fn(i, shape) if noise_fn is not None else None
+            if self.multicond:  # (ddim_multiplecond.py:190-196: these two reach p_sample_ddim there)
+                model_kwargs = dict(model_kwargs, cfg_img=kwargs.get("cfg_img"),
+                                    unconditional_conditioning_img_nonetext=kwargs.get("unconditional_conditioning_img_nonetext"))
             img, pred_x0 = self.p_sample_ddim(img, cond, ts, index, temperature=temperature,
                                               unconditional_guidance_scale=unconditional_guidance_scale,
                                               unconditional_conditioning=unconditional_conditioning, fs=fs,
@@ -569,3 +606,18 @@ class DDIMSampler:
         if precision is not None and isinstance(precision, torch.dtype):
             img = img.to(precision)
         return img, intermediates
+
+
+class DDIMSamplerMultiCond(DDIMSampler):
+    """The multi-condition sampler (drop-in for lvdm.models.samplers.ddim_multiplecond.DDIMSampler, selected by
+    `multiple_cond_cfg=True`, model.py:705): THREE U-Net forwards per step - conditional, unconditional and "image
+    tokens + empty text" (`unconditional_conditioning_img_nonetext`, model.py:737-743) - combined as
+        v = e_uc + cfg_img (e_uc_img - e_uc) + scale (e_c - e_uc_img)        (ddim_multiplecond.py:233-234)
+    with `cfg_img` defaulting to the text scale (:219-220); everything after the combine is the step of the main
+    sampler.  In the reference checkout this class is dead on arrival: its make_schedule runs np.sqrt on the bf16
+    `alphas_cumprod` buffer and raises TypeError (ddim_multiplecond.py:40; pinned by tests/test_oracle_vs_reference.py).
+    The working form - what upstream DynamiCrafter's f32-buffer model runs - is its own sample / ddim_sampling /
+    p_sample_ddim on top of the one-line cast the main sampler already has (`alphas_cumprod.to(torch.float32)`,
+    ddim.py:27): that recombination of the reference's own code is the parity oracle (oracle/make_golden.py
+    gen_ddim_multicond), and this class restates it on the fused update kernel and the three-forward HIP graph."""
+    multicond = True

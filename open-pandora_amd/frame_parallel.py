@@ -193,6 +193,23 @@ class PeerMailbox:
         return tot, lo, hi
 
 
+_COMM_STREAMS = {}
+
+
+def _on_comm_stream(fn):
+    """Run an RCCL call on the process's dedicated communication stream of the current device, joined to the caller's stream
+    by events on both sides (why: FrameParallel._comm)."""
+    cur = torch.cuda.current_stream()
+    key = cur.device.index
+    cs = _COMM_STREAMS.get(key)
+    if cs is None:
+        cs = _COMM_STREAMS[key] = torch.cuda.Stream(device=cur.device)
+    cs.wait_stream(cur)
+    with torch.cuda.stream(cs):
+        fn()
+    cur.wait_stream(cs)
+
+
 def _host_staged_sync(t, group=None):
     """gloo (the CPU-test / single-GPU rehearsal backend) stages CUDA tensors through the host without
     ordering against the producing stream; RCCL ("nccl") is stream-ordered and needs nothing."""
@@ -241,15 +258,28 @@ class FrameParallel:
 
     def _comm(self, fn):
         """Issue one torch.distributed exchange - or hand it to the recording _SegmentedForward, which re-issues the same
-        closure at every replay.  gloo stages device tensors through the host without ordering against the stream that
-        produced them: there the closure itself waits for the stream first (inside the closure, so that replays do it too;
-        RCCL is stream-ordered and needs nothing)."""
-        if self.backend != "nccl" and torch.cuda.is_available() and torch.cuda.is_initialized():
-            inner = fn
+        closure at every replay.
 
-            def fn():
-                torch.cuda.current_stream().synchronize()
-                inner()
+        RCCL ("nccl"): the call is issued on a DEDICATED stream that is joined to the caller's stream by events on both
+        sides, never on the caller's stream itself.  ProcessGroupNCCL's watchdog thread polls the end event of every
+        collective, and on this HIP runtime hipEventQuery fails (hipErrorCapturedEvent) for an event whose recording
+        stream is capturing AT THE TIME OF THE QUERY - even if the record happened before the capture began
+        (tools/diag/event_query_probe.py).  The segmented replay captures on the very stream its warm-up forward ran on:
+        a watchdog poll that fell into that window raised inside the watchdog thread, and ProcessGroupNCCL then
+        terminated the process (the r03 abort of tests/test_segmented_gpu.py: SIGABRT in torch.cat /
+        destroy_process_group, 1 run in 4).  The dedicated stream never captures, so its events are always queryable.
+
+        gloo stages device tensors through the host without ordering against the stream that produced them: there the
+        closure itself waits for the stream first (inside the closure, so that replays do it too)."""
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            inner = fn
+            if self.backend == "nccl":
+                def fn():  # (buffers stay owned by the caller's stream: the comm stream is joined back before any reuse)
+                    _on_comm_stream(inner)
+            else:
+                def fn():
+                    torch.cuda.current_stream().synchronize()
+                    inner()
         if self.recorder is None:
             fn()
         else:
@@ -268,15 +298,22 @@ class FrameParallel:
     def gather_frames(self, x_local, dim=2):
         """inverse of shard_frames: every rank receives the whole clip."""
         parts = [torch.empty_like(x_local) for _ in range(self.world)]
-        _host_staged_sync(x_local, self.group)
-        dist.all_gather(parts, x_local.contiguous(), group=self.group)
+        src = x_local.contiguous()
+        rec, self.recorder = self.recorder, None  # (a sampler-level collective: never part of a recorded forward)
+        try:
+            self._comm(lambda: dist.all_gather(parts, src, group=self.group))
+        finally:
+            self.recorder = rec
         return torch.cat(parts, dim=dim)
 
     def all_reduce_sum(self, t):
         """sum over the frame group (sampler-level reductions, e.g. the std of rescale_noise_cfg)"""
         t = t.contiguous().clone()
-        _host_staged_sync(t, self.group)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        rec, self.recorder = self.recorder, None
+        try:
+            self._comm(lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group))
+        finally:
+            self.recorder = rec
         return t
 
     def _mailbox_exchange(self, stats, first=None, last=None):
@@ -416,8 +453,14 @@ class CFGParallel:
         e_other = torch.empty_like(e_mine)
         _host_staged_sync(e_mine)
         ops = [dist.P2POp(dist.isend, e_mine, self.partner), dist.P2POp(dist.irecv, e_other, self.partner)]
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+
+        def go():
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if e_mine.is_cuda and dist.get_backend() == "nccl":
+            _on_comm_stream(go)  # (RCCL calls never run on a stream that may capture: FrameParallel._comm)
+        else:
+            go()
         return (e_mine, e_other) if self.branch == 0 else (e_other, e_mine)
 
 

@@ -514,10 +514,10 @@ class UNetModel(packing.PackedWeights, nn.Module):
                 c.H, c.W = (c.H + 1) // 2, (c.W + 1) // 2
             elif isinstance(layer, Upsample):
                 wp, b = c.w[self._names[layer]]
-                # (frame shards keep the gathered form: with the written-out interpolation tests/test_segmented_gpu.py aborted in
-                # 2 of 3 runs - unexplained, DESIGN.md section 6 - and the sharded path cannot be re-validated on one GPU this round)
-                kw = {} if c.fp is None else {"presplit_upsample": False}
-                h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W, upsample=True, stream=True, out=dst, **kw)
+                # (r03 kept the gathered form for frame shards because tests/test_segmented_gpu.py aborted with the written-out
+                # interpolation; the abort was the process group's watchdog querying an event of a capturing stream -
+                # frame_parallel.FrameParallel._comm - and had nothing to do with this op: one form everywhere again)
+                h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W, upsample=True, stream=True, out=dst)
                 c.H, c.W = 2 * c.H, 2 * c.W
             elif isinstance(layer, nn.Conv2d):  # stem
                 wp, b = c.w["stem"]

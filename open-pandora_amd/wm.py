@@ -19,7 +19,7 @@ the latents are returned (that is what bench.py and the parity tests consume).
 import torch
 from einops import repeat
 
-from .ddim import DDIMSampler
+from .ddim import DDIMSampler, DDIMSamplerMultiCond
 
 
 def get_latent_z(encode_first_stage, videos):
@@ -42,12 +42,11 @@ def _synthesize(diffusion_model, diffusion_conditioning, img_emb, uc_text_emb, u
     """model.py:703-781 with the encoders factored out (private core of `DiffusionRunner.image_guided_synthesis`).
     Returns (batch, n_samples, c, t, h, w): decoded frames if `decode_first_stage` is given, else latents."""
     if multiple_cond_cfg:
-        # SURVEY §8f row 4.  The reference's DDIMSampler_multicond cannot run on this model either: its
-        # make_schedule (ddim_multiplecond.py:40) calls np.sqrt on the bf16 alphas_cumprod buffer that
-        # DDPM.register_schedule leaves behind (ddpm3d.py:159) and raises "Got unsupported ScalarType
-        # BFloat16" (pinned by tests/test_oracle_vs_reference.py), so there is no behaviour to match.
-        raise NotImplementedError("multiple_cond_cfg: the reference's DDIMSampler_multicond raises TypeError on the "
-                                  "bf16 schedule buffers (ddim_multiplecond.py:40); no three-way CFG path exists")
+        # model.py:705: the multi-condition sampler (SURVEY §8f row 4).  The reference's own class cannot run on this fork's
+        # bf16 schedule buffers (ddim_multiplecond.py:40 raises TypeError: pinned by tests/test_oracle_vs_reference.py);
+        # DDIMSamplerMultiCond is its working form (see that class), so the flag now does what model.py:737-743 intends
+        if not isinstance(sampler, DDIMSamplerMultiCond):
+            sampler = DDIMSamplerMultiCond(diffusion_model)
     sampler = sampler or DDIMSampler(diffusion_model)
     batch_size = noise_shape[0]
     dev = z_cond.device
@@ -56,7 +55,11 @@ def _synthesize(diffusion_model, diffusion_conditioning, img_emb, uc_text_emb, u
     uc = None
     if unconditional_guidance_scale != 1.0:
         uc = {"c_crossattn": [torch.cat([uc_text_emb, uc_img_emb], dim=1)], "c_concat": [z_cond]}
-    kwargs.update({"unconditional_conditioning_img_nonetext": None})
+    # model.py:736-743: one more unconditional set - image tokens kept, text empty - for the multi-condition sampler
+    uc_2 = None
+    if multiple_cond_cfg and cfg_img != 1.0 and unconditional_guidance_scale != 1.0:
+        uc_2 = {"c_crossattn": [torch.cat([uc_text_emb, img_emb], dim=1)], "c_concat": [z_cond]}
+    kwargs.update({"unconditional_conditioning_img_nonetext": uc_2})
     variants = []
     for _ in range(n_samples):  # independent replicas (model.py:749)
         samples, _ = sampler.sample(S=ddim_steps, conditioning=cond, batch_size=batch_size, shape=noise_shape[1:],

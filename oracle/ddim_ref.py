@@ -8,7 +8,8 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 Reference call sites (relative to /root/reference/DynamiCrafter/lvdm):
   schedule_tables   models/ddpm3d.py:119-182,505-510; models/utils_diffusion.py:31-36,112-144
   ddim_tables       models/samplers/ddim.py:24-63; models/utils_diffusion.py:56-91
-  ddim_sample       models/samplers/ddim.py:141-215 (loop), :218-290 (one step), ddpm3d.py:235-247
+  ddim_sample       models/samplers/ddim.py:141-215 (loop), :218-290 (one step), ddpm3d.py:235-247;
+                    `uncond_img` given: the three-way combine of models/samplers/ddim_multiplecond.py:229-236
 """
 import numpy as np
 import torch
@@ -53,7 +54,7 @@ def ddim_tables(tables, S, eta, spacing):
 
 @torch.no_grad()
 def ddim_sample(apply_model, tables, x_T, cond, uncond, S, eta, cfg_scale, spacing="uniform_trailing",
-                noises=None, fs=None, keep_pred_x0=False, guidance_rescale=0.0):
+                noises=None, fs=None, keep_pred_x0=False, guidance_rescale=0.0, uncond_img=None, cfg_img=None):
     """apply_model(x, t, cond, fs) -> v prediction.  noises: list of S tensors (one per loop
     iteration, same shape as x_T) consumed when eta > 0.  Returns (x_0 sample, [pred_x0 per step])."""
     d = ddim_tables(tables, S, eta, spacing)
@@ -68,6 +69,15 @@ def ddim_sample(apply_model, tables, x_T, cond, uncond, S, eta, cfg_scale, spaci
         e_c = apply_model(x, t, cond, fs)
         if uncond is None or cfg_scale == 1.0:
             v = e_c
+        elif uncond_img is not None:  # multi-condition sampler (ddim_multiplecond.py:229-236): text on top of image guidance
+            e_u = apply_model(x, t, uncond, fs)
+            e_ui = apply_model(x, t, uncond_img, fs)
+            ci = cfg_scale if cfg_img is None else cfg_img
+            v = e_u + ci * (e_ui - e_u) + cfg_scale * (e_c - e_ui)
+            if guidance_rescale > 0.0:
+                dims = list(range(1, v.dim()))
+                resc = v * (e_c.std(dim=dims, keepdim=True) / v.std(dim=dims, keepdim=True))
+                v = guidance_rescale * resc + (1 - guidance_rescale) * v
         else:
             e_u = apply_model(x, t, uncond, fs)
             v = e_u + cfg_scale * (e_c - e_u)

@@ -13,6 +13,8 @@ UNET_CTX_CASES = ((82, "ctx82_shared_image_tokens"), (77, "ctx77_text_only"))
 DDIM_SMALL_CASES = ((5, 0.0, 4.0), (10, 0.0, 4.0), (20, 1.0, 4.0), (10, 0.0, 1.0), (10, 1.0, 4.0))
 FRAMES_SMALL_CASES = ((5, 0.0), (50, 1.0))  # (S, eta): sampler -> decode_first_stage, cfg 4
 DDIM_RESCALE_CASES = ((5, 0.0, 4.0, 0.7), (20, 1.0, 4.0, 0.3))  # (S, eta, cfg, guidance_rescale)
+# the multi-condition sampler (ddim_multiplecond.py): (S, eta, cfg, cfg_img or None = "same as cfg", guidance_rescale)
+DDIM_MULTICOND_CASES = ((5, 0.0, 4.0, 2.0, 0.0), (20, 1.0, 7.5, None, 0.7))
 
 # (tag, constructor kwargs, x shape): a reduced Resampler and the shipped image_proj_stage_config
 RESAMPLER_CASES = (("small", dict(dim=128, depth=2, dim_head=64, heads=2, num_queries=4, embedding_dim=192,
@@ -29,6 +31,14 @@ def module_inputs():
     return {"x4": module_input("mod/x4", 16, 64, 4, 6), "x5": module_input("mod/x5", 1, 64, 16, 4, 6),
             "tok": module_input("mod/tok", 16, 24, 128), "ctx": module_input("mod/ctx", 16, 77 + 16, 1024),
             "emb": module_input("mod/emb", 16, 256)}
+
+
+def multicond_uc_img(ins, cond, uc):
+    """`unconditional_conditioning_img_nonetext` as model.py:737-743 builds it: the unconditional TEXT tokens followed by the
+    conditional IMAGE tokens (text = first 77 tokens of c_crossattn)."""
+    import torch
+    return {"c_crossattn": [torch.cat([uc["c_crossattn"][0][:, :77], cond["c_crossattn"][0][:, 77:]], dim=1)],
+            "c_concat": list(cond["c_concat"])}
 
 
 def sampler_inputs(h, w, T=16):

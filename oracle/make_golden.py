@@ -170,6 +170,39 @@ def gen_ddim_rescale():
     save("ddim_small_rescale.npz", **out)
 
 
+def gen_ddim_multicond():
+    """The multi-condition sampler (lvdm/models/samplers/ddim_multiplecond.py, selected by model.py:705).  As shipped it dies
+    in make_schedule (np.sqrt on the bf16 alphas_cumprod buffer, :40: pinned by tests/test_oracle_vs_reference.py); its
+    WORKING form is its own sample / ddim_sampling / p_sample_ddim (three forwards per step, :229-236) on top of the main
+    sampler's make_schedule, which differs from :24-57 only by the cast this fork added there (`alphas_cumprod.to(float32)`,
+    ddim.py:27).  Both halves are the reference's code, recombined here by inheritance - nothing is restated."""
+    rh._install_shims()
+    import lvdm.models.samplers.ddim as refddim
+    import lvdm.models.samplers.ddim_multiplecond as refmc
+
+    class WorkingMultiCond(refmc.DDIMSampler):
+        make_schedule = refddim.DDIMSampler.make_schedule
+
+        def register_buffer(self, name, attr):  # (bypasses the hard-coded `cuda`, as rh.reference_sampler does)
+            setattr(self, name, attr)
+
+    out = {}
+    m = rh.reference_diffusion(dict(model_channels=64))
+    m.model.diffusion_model.load_state_dict(synth.synth_state_dict(m.model.diffusion_model, seed=WEIGHT_SEED))
+    ins, cond, uc = _small_setup()
+    uc_img = gr.multicond_uc_img(ins, cond, uc)
+    for S, eta, cfg, cfg_img, gres in gr.DDIM_MULTICOND_CASES:
+        noises = iter(gr.noises(ins["x_T"].shape, S))
+        refmc.noise_like = lambda shape, device, repeat=False: next(noises)
+        y, _ = WorkingMultiCond(m).sample(S=S, batch_size=1, shape=(4, 16, 8, 8), conditioning=cond, verbose=False,
+                                          unconditional_guidance_scale=cfg, unconditional_conditioning=uc, eta=eta,
+                                          fs=torch.tensor([15]), timestep_spacing="uniform_trailing", x_T=ins["x_T"],
+                                          guidance_rescale=gres, cfg_img=cfg_img,
+                                          unconditional_conditioning_img_nonetext=uc_img)
+        out[f"S{S}_eta{eta:g}_cfg{cfg:g}_img{cfg_img}_gr{gres:g}"] = y.numpy()
+    save("ddim_small_multicond.npz", **out)
+
+
 def gen_resampler():
     """The real Resampler (resampler.py:96-144) on seeded weights: reduced config in full, the shipped
     image_proj_stage_config (inference_512_v1.0.yaml:91-102) as a digest."""
@@ -395,6 +428,7 @@ if __name__ == "__main__":
     ap.add_argument("--oracle-72x128", action="store_true")
     ap.add_argument("--ae", action="store_true")
     ap.add_argument("--rescale", action="store_true")
+    ap.add_argument("--multicond", action="store_true")
     ap.add_argument("--resampler", action="store_true")
     ap.add_argument("--frames", action="store_true", help="reduced-width sampler -> decode_first_stage frames (seconds)")
     ap.add_argument("--frames-full", default="", help='full-width cases "S:eta,S:eta", e.g. "10:0,50:1" (hours of CPU)')
@@ -425,6 +459,10 @@ if __name__ == "__main__":
         assert rh.available()
         gen_ddim_rescale()
         sys.exit(0)
+    if a.multicond:
+        assert rh.available()
+        gen_ddim_multicond()
+        sys.exit(0)
     if a.ae:
         assert rh.available()
         gen_ae()
@@ -442,3 +480,4 @@ if __name__ == "__main__":
         gen_unet_ctx()
         gen_ddim_small()
         gen_ddim_rescale()
+        gen_ddim_multicond()

@@ -4,6 +4,11 @@ import sys
 import pytest
 import torch  # noqa: F401  (before anything loads libpandora_mi355x.so: one HIP runtime per process)
 
+# Eager PyTorch on the many small ops of the CPU oracle scales NEGATIVELY past ~16 threads (bench.py cpu_baseline, measured on
+# the GPU box's 2 x 64-core host: 16 threads 3.8 s, 128 threads 25.7 s for the same U-Net forward): cap the pool for the whole
+# session - the oracle sides of the GPU parity tests are a large part of the suite's wall time.
+torch.set_num_threads(min(16, os.cpu_count() or 16))
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -128,6 +128,28 @@ def test_ddim_guidance_rescale_against_reference(S, eta, cfg, gres):
     assert np.isfinite(g).all() and rel(y, g) < 5e-5
 
 
+@pytest.mark.parametrize("S,eta,cfg,cfg_img,gres", gr.DDIM_MULTICOND_CASES)
+def test_ddim_multicond_against_reference(S, eta, cfg, cfg_img, gres):
+    """The multi-condition sampler (ddim_multiplecond.py:214-236, three forwards per step): the oracle's restatement against
+    the fixture produced by the reference's own sample / ddim_sampling / p_sample_ddim (oracle/make_golden.py
+    gen_ddim_multicond: on top of the main sampler's make_schedule - the shipped one dies on the bf16 buffers)."""
+    g = load("ddim_small_multicond.npz")[f"S{S}_eta{eta:g}_cfg{cfg:g}_img{cfg_img}_gr{gres:g}"]
+    kw = dict(RH_KW, model_channels=64)
+    sd = _sd(U.UNetModel(**kw))
+    ins, cond, uc = gr.sampler_inputs(8, 8)
+    apply = lambda x, t, c, fs: unet_ref.unet_forward(sd, torch.cat([x] + c["c_concat"], 1), t,
+                                                      torch.cat(c["c_crossattn"], 1), fs, model_channels=64)
+    y, _ = ddim_ref.ddim_sample(apply, ddim_ref.schedule_tables(), ins["x_T"], cond, uc, S, eta, cfg,
+                                noises=gr.noises(ins["x_T"].shape, S), fs=torch.tensor([15]), guidance_rescale=gres,
+                                uncond_img=gr.multicond_uc_img(ins, cond, uc), cfg_img=cfg_img)
+    assert np.isfinite(g).all() and rel(y, g) < 5e-5
+    # against the two-way sampler: with cfg_img == cfg (the default, ddim_multiplecond.py:219-220) the image-only forward
+    # cancels algebraically - the same result up to f32 rounding - otherwise the third forward matters
+    y2, _ = ddim_ref.ddim_sample(apply, ddim_ref.schedule_tables(), ins["x_T"], cond, uc, S, eta, cfg,
+                                 noises=gr.noises(ins["x_T"].shape, S), fs=torch.tensor([15]), guidance_rescale=gres)
+    assert (rel(y2, g) < 5e-5) if cfg_img is None else (rel(y2, g) > 1e-2)
+
+
 def test_oracle_72x128_fixture_matches_the_real_reference():
     """Two committed digests of the same full-width forward at 16x72x128: one from the oracle (chunked attention),
     one from the REAL reference (eager attention called per frame, oracle/make_golden.py --full-72x128)."""

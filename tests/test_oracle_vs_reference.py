@@ -1,6 +1,7 @@
 """Build-container only: the oracle against the LIVE reference implementation imported from
 /root/reference (skipped where the checkout is absent, e.g. on the GPU box - the same comparison is
 then carried by the committed fixtures, tests/test_oracle_golden.py)."""
+import numpy as np
 import pytest
 import torch
 
@@ -38,13 +39,13 @@ def test_fixture_regeneration_is_reproducible(tmp_path, monkeypatch):
         assert np.array_equal(new[k], old[k], equal_nan=True), k
 
 
-def test_multicond_sampler_is_dead_in_the_reference():
-    """`multiple_cond_cfg=True` selects ddim_multiplecond.DDIMSampler (model.py:705), whose
-    make_schedule runs np.sqrt on the bf16 `alphas_cumprod` buffer and raises; our wm layer therefore
-    refuses the flag instead of inventing a behaviour."""
+def test_multicond_sampler_is_dead_in_the_reference_and_its_working_form_is_ours(tmp_path, monkeypatch):
+    """`multiple_cond_cfg=True` selects ddim_multiplecond.DDIMSampler (model.py:705), whose make_schedule
+    runs np.sqrt on the bf16 `alphas_cumprod` buffer and raises - as shipped, the class is dead.  Its working form (its own
+    sampling code on the main sampler's make_schedule, regenerated here live) is what the product's DDIMSamplerMultiCond
+    and the committed fixture restate."""
     rh._install_shims()
     import lvdm.models.samplers.ddim_multiplecond as refmc
-    from open_pandora_amd import wm
 
     class CPUSampler(refmc.DDIMSampler):
         def register_buffer(self, name, attr):
@@ -54,5 +55,13 @@ def test_multicond_sampler_is_dead_in_the_reference():
     assert m.alphas_cumprod.dtype == torch.bfloat16
     with pytest.raises(TypeError, match="BFloat16"):
         CPUSampler(m).make_schedule(5, "uniform_trailing", 0.0, verbose=False)
-    with pytest.raises(NotImplementedError, match="multiple_cond_cfg"):
-        wm._synthesize(None, None, None, None, None, None, (1, 4, 16, 8, 8), multiple_cond_cfg=True)
+    import os
+    from oracle import golden_recipe as gr
+    from oracle import make_golden as mg
+    monkeypatch.setattr(mg, "GOLD", str(tmp_path))
+    monkeypatch.setattr(gr, "DDIM_MULTICOND_CASES", gr.DDIM_MULTICOND_CASES[:1])
+    mg.gen_ddim_multicond()
+    new = np.load(tmp_path / "ddim_small_multicond.npz")
+    old = np.load(os.path.join(os.path.dirname(__file__), "golden", "ddim_small_multicond.npz"))
+    for k in new.files:
+        assert np.array_equal(new[k], old[k]), k

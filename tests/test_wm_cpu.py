@@ -70,3 +70,34 @@ def test_multiround_driver_conditions_each_round_on_the_previous_frames():
     r1_last4 = out[0, 0][:, 8:12]  # (frames 12-15 of round 1 are cut by the stitching: recompute from round 2's input)
     assert seen[1].abs().max() <= 1.0 and torch.allclose(seen[1] * 127.5 + 127.5, (seen[1] * 127.5 + 127.5).round(), atol=1e-3)
     assert r1_last4.shape[1] == 4
+
+
+def test_multiple_cond_cfg_selects_the_three_forward_sampler():
+    """model.py:705,737-743 + ddim_multiplecond.py:214-236: `multiple_cond_cfg=True` through the caller surface builds the
+    image-tokens-with-empty-text condition set and runs THREE forwards per step; the product sampler (on the oracle's op
+    table here) reproduces the fixture of the reference's own sampling code (oracle/make_golden.py gen_ddim_multicond)."""
+    from test_oracle_golden import load, rel
+    torch.set_num_threads(4)
+    S, eta, cfg, cfg_img, gres = gr.DDIM_MULTICOND_CASES[0]
+    g = load("ddim_small_multicond.npz")[f"S{S}_eta{eta:g}_cfg{cfg:g}_img{cfg_img}_gr{gres:g}"]
+    m = UNetModel(**dict(RH_KW, model_channels=64)).eval()
+    m.load_state_dict(synth.synth_state_dict(m, seed=gr.WEIGHT_SEED))
+    pm = LatentVisualDiffusion(m.bind(TorchOps()))
+    calls = []
+    inner = pm.apply_model
+    pm.apply_model = lambda x, t, c, **kw: (calls.append(c["c_crossattn"][0]), inner(x, t, c, **kw))[1]
+    ins, cond, uc = gr.sampler_inputs(8, 8)
+    text, img = ins["c_crossattn"][:, :77], ins["c_crossattn"][:, 77:]
+    uct, uci = ins["uc_crossattn"][:, :77], ins["uc_crossattn"][:, 77:]
+    y = wm._synthesize(pm, text, img, uct, uci, ins["c_concat"], (1, 4, 16, 8, 8), n_samples=1, ddim_steps=S, ddim_eta=eta,
+                       unconditional_guidance_scale=cfg, cfg_img=cfg_img, fs=15, multiple_cond_cfg=True,
+                       timestep_spacing="uniform_trailing", guidance_rescale=gres, x_T=ins["x_T"])[:, 0]
+    assert rel(y, g) < 5e-5
+    assert len(calls) == 3 * S
+    want_ui = gr.multicond_uc_img(ins, cond, uc)["c_crossattn"][0]
+    assert torch.equal(calls[2], want_ui) and torch.equal(calls[0], cond["c_crossattn"][0]) and torch.equal(calls[1], uc["c_crossattn"][0])
+    # without the flag: the two-forward sampler, as before
+    calls.clear()
+    wm._synthesize(pm, text, img, uct, uci, ins["c_concat"], (1, 4, 16, 8, 8), n_samples=1, ddim_steps=2, ddim_eta=0.0,
+                   unconditional_guidance_scale=cfg, fs=15, timestep_spacing="uniform_trailing", x_T=ins["x_T"])
+    assert len(calls) == 2 * 2

@@ -1,0 +1,50 @@
+"""Root cause of the r03 abort of tests/test_segmented_gpu.py, isolated (VERDICT r03 #1 ii).
+
+ProcessGroupNCCL's watchdog thread polls the end event of every collective with hipEventQuery.  On this HIP runtime the
+query of an event fails with hipErrorCapturedEvent ("operation not permitted on an event last recorded in a capturing
+stream") when the stream the event was recorded on is CAPTURING at the time of the query - also when the record itself
+happened before the capture began (CUDA only refuses events recorded DURING a capture).  ddim._SegmentedForward issued its
+warm-up forward - and with it RCCL calls - on the stream it captures on right afterwards: whenever the watchdog's 100-ms
+poll fell between the last warm-up collective and its clean-up, the query raised inside the watchdog thread and
+ProcessGroupNCCL terminated the process from there (SIGABRT wherever the main thread happened to be: torch.cat,
+destroy_process_group).  This probe reproduces the runtime behaviour without RCCL: an event recorded on a stream BEFORE a
+thread-local capture of that stream begins is queried from a second thread during the capture.
+
+usage: python tools/diag/event_query_probe.py"""
+import threading
+
+import torch
+
+dev = torch.device("cuda:0")
+side, other = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+x = torch.zeros(1 << 20, device=dev)
+
+
+def query_from_thread(ev):
+    out = {}
+
+    def run():
+        try:
+            out["done"] = ev.query()
+        except Exception as exc:  # noqa: BLE001
+            out["error"] = str(exc).splitlines()[0]
+    th = threading.Thread(target=run)
+    th.start()
+    th.join()
+    return out
+
+
+for name, rec_stream in (("event recorded on the stream that later captures", side),
+                         ("event recorded on another stream", other)):
+    ev = torch.cuda.Event()
+    with torch.cuda.stream(rec_stream):
+        x.add_(1.0)
+        ev.record(rec_stream)
+    torch.cuda.synchronize()
+    before = query_from_thread(ev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+        x.add_(1.0)
+        during = query_from_thread(ev)
+    after = query_from_thread(ev)
+    print(f"{name}: query before capture {before} | DURING the capture of `side` {during} | after {after}")
