@@ -21,6 +21,8 @@ SOURCES = ["gemm.hip", "gemm256.hip", "lngemm.hip", "attn.hip", "attn16.hip", "n
 HEADERS = ["common.hpp", "gemm_common.hpp", "attn_common.hpp", os.path.join("..", "..", "include", "pandora_mi355x.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 LDFLAGS = ["--offload-arch=gfx950", "-fPIC", "-shared"]
+# attn16.hip: no SLP vectoriser (it packs the softmax row sums of the two query blocks into v_pk_add_f32: see the file)
+PER_FILE_FLAGS = {"attn16.hip": ["-fno-slp-vectorize"]}
 FLAGS = CFLAGS + LDFLAGS  # (kept: tools that quote the build line)
 
 
@@ -48,7 +50,7 @@ def _unit_digest(src, cflags):
     seen = _includes(os.path.join(CSRC, src), {})
     for path in sorted(seen):
         h.update(seen[path])
-    h.update(" ".join(cflags).encode())
+    h.update(" ".join(cflags + PER_FILE_FLAGS.get(src, [])).encode())
     return h.hexdigest()
 
 
@@ -86,7 +88,7 @@ def build(force=False, verbose=False, diag=False, jobs=None):
             with open(obj + ".stamp") as f:
                 if f.read().strip() == ud:
                     return obj
-        cmd = [hipcc] + cflags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + cflags + PER_FILE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)

@@ -1137,7 +1137,8 @@ extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const voi
                                        (hipStream_t)stream, p);                                                    \
                     return check_launch())
 #ifdef PM_DIAG
-  if (variant == 16) return launch_attn_self16(p, dtype, grid, (hipStream_t)stream);  // the 16x16x32-MFMA form (attn16.hip)
+  if (variant == 16 || variant == 17)  // the 16x16x32-MFMA form (attn16.hip) at 3 / 4 waves per SIMD
+    return launch_attn_self16(p, dtype, grid, (hipStream_t)stream, variant == 17 ? 4 : 3);
   if (variant == 9)  // (kept for A/B runs: the round-1 kernel)
     PM_DISPATCH_DTYPE(dtype, T,
                       hipLaunchKernelGGL((attn_kernel<T, 1, false>), grid, dim3(256), 0, (hipStream_t)stream, p);

@@ -26,17 +26,14 @@ namespace pm {
 constexpr float STALE_THR16 = 6.0f;
 
 __device__ __forceinline__ float xor16(float v) { return __shfl_xor(v, 16, 64); }
-// one v_add_f32, opaque to the SLP vectoriser: plain -O3 packs the row-sum chains of the two query blocks into v_pk_add_f32,
-// which costs ~13 cycles each beside MFMAs instead of 4 (MI355X_MICROARCH.md, price of one filler).  Inputs are v_exp
-// results (VALU -> VALU: no software hazard for an asm statement to miss).
-__device__ __forceinline__ float add1(float a, float b) {
-  float r;
-  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
+// (This file is compiled with -fno-slp-vectorize, build.py PER_FILE_FLAGS: plain -O3 packs the row-sum chains of the two query
+// blocks into v_pk_add_f32, which costs ~13 cycles each beside MFMAs instead of 4 - MI355X_MICROARCH.md, price of one filler.
+// An inline-asm v_add_f32 is NOT the way to keep them single: hipcc inserts no wait state between a transcendental result
+// (v_exp_f32) and an asm statement that reads it - gfx950's trans-forwarding hazard - and the sums come out wrong.)
 
-template <typename T>
-__global__ __launch_bounds__(256, 3) void attn_self16_kernel(const AttnParams p) {
+// WPS: waves per SIMD the register allocation is held to (3: <= 168 VGPRs, 4: <= 128 - one more workgroup per CU)
+template <typename T, int WPS>
+__global__ __launch_bounds__(256, WPS) void attn_self16_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE_BYTES];  // K[2], V[2]
   char* const Ks = smem;
   char* const Vs = smem + 2 * KV_TILE_BYTES;
@@ -211,10 +208,10 @@ __global__ __launch_bounds__(256, 3) void attn_self16_kernel(const AttnParams p)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float pe = __builtin_amdgcn_exp2f(sacc[kb][qb][r]);
-          ps[r] = kb ? add1(ps[r], pe) : pe;
+          ps[r] = kb ? ps[r] + pe : pe;
           pf[kb >> 1][qb].e[4 * (kb & 1) + r] = from_f32<T>(pe);
         }
-      l_run[qb] = add1(l_run[qb], add1(add1(ps[0], ps[1]), add1(ps[2], ps[3])));
+      l_run[qb] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
     }
     // ---- O^T += V^T . P^T ----
 #pragma unroll
@@ -239,12 +236,8 @@ __global__ __launch_bounds__(256, 3) void attn_self16_kernel(const AttnParams p)
   arrive(0);
   tile(0, std::integral_constant<int, 0>{}, std::true_type{});
   int kt = 1;
-  for (; kt + 1 < last_full; kt += 2) {  // two tiles per trip: every tile's stage is a compile-time constant
-    arrive(kt);
-    tile(kt, std::integral_constant<int, 1>{}, std::false_type{});
-    arrive(kt + 1);
-    tile(kt + 1, std::integral_constant<int, 0>{}, std::false_type{});
-  }
+  // (one tile per trip, stage = kt & 1 at run time: unrolled by two - stages as compile-time constants - hipcc hoists both
+  // stages' fragment reads across the trip and spills 22 registers at 168; this form holds 120, no scratch)
   for (; kt < last_full; ++kt) {
     arrive(kt);
     tile(kt, kt & 1, std::false_type{});
@@ -279,15 +272,16 @@ __global__ __launch_bounds__(256, 3) void attn_self16_kernel(const AttnParams p)
   }
 }
 
-template __global__ void attn_self16_kernel<f16>(const AttnParams);
-template __global__ void attn_self16_kernel<bf16>(const AttnParams);
 
 }  // namespace pm
 
 // launcher used by pm_attention (attn.hip)
 namespace pm {
-int launch_attn_self16(const AttnParams& p, int dtype, dim3 grid, hipStream_t stream) {
-  PM_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_self16_kernel<T>), grid, dim3(256), 0, stream, p);
+int launch_attn_self16(const AttnParams& p, int dtype, dim3 grid, hipStream_t stream, int waves_per_simd) {
+  if (waves_per_simd == 4)
+    PM_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_self16_kernel<T, 4>), grid, dim3(256), 0, stream, p);
+                      return check_launch());
+  PM_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_self16_kernel<T, 3>), grid, dim3(256), 0, stream, p);
                     return check_launch());
 }
 }  // namespace pm

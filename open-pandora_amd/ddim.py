@@ -64,8 +64,26 @@ class _ForwardGraph:
         self.x = x.clone()
         self.t = t.clone()
         dev = x.device
-        two = uc is not None and os.environ.get("PANDORA_CFG_STREAMS", "1") != "0"
         side, other = _capture_streams(dev)
+        # PANDORA_CFG_BATCH=1: the cond / uncond pair as ONE forward over 2 x T frames (UNetModel batches the clips along the
+        # rows: weights read once, grids twice as full) instead of two forwards on two streams
+        self.batched = (uc is not None and not extra and os.environ.get("PANDORA_CFG_BATCH", "0") == "1"
+                        and isinstance(c, dict) and set(c) == set(uc) and x.shape[0] == 1)
+        if self.batched:
+            cc = {k: [torch.cat([a, b_], 0) for a, b_ in zip(c[k], uc[k])] for k in c}  # (static copies: the graph reads these)
+            self.x = torch.cat([x, x], 0)
+            self.t = torch.cat([t, t], 0)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):  # warm-up outside capture
+                model.apply_model(self.x, self.t, cc, fs=fs, **kwargs)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
+                out = model.apply_model(self.x, self.t, cc, fs=fs, **kwargs)
+            self.e_c, self.e_u, self.e_x = out[0:1], out[1:2], []
+            return
+        two = uc is not None and os.environ.get("PANDORA_CFG_STREAMS", "1") != "0"
         if not two:
             other = None
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -98,8 +116,13 @@ class _ForwardGraph:
                 self.e_u = model.apply_model(self.x, self.t, uc, fs=fs, **kwargs) if uc is not None else None
 
     def __call__(self, x, t):
-        self.x.copy_(x)
-        self.t.copy_(t)
+        if self.batched:
+            self.x[0:1].copy_(x)
+            self.x[1:2].copy_(x)
+            self.t.copy_(t.expand(2))
+        else:
+            self.x.copy_(x)
+            self.t.copy_(t)
         self.graph.replay()
         return self.e_c, self.e_u
 
@@ -397,8 +420,8 @@ class DDIMSampler:
                        + ([fs] if torch.is_tensor(fs) else []))
             # (a weight reload / .to() re-packs the kernel-side weights: the captured graph holds raw pointers to the
             # old ones, so the U-Net's pack epoch is part of the key)
-            key = (tuple(x.shape), tuple((v.data_ptr(), tuple(v.shape)) for v in tensors), tuple(sorted(kwargs)),
-                   getattr(unet, "_pack_epoch", 0))
+            key = (tuple(x.shape), tuple((v.data_ptr(), tuple(v.shape), v._version) for v in tensors), tuple(sorted(kwargs)),
+                   getattr(unet, "_pack_epoch", 0), os.environ.get("PANDORA_CFG_BATCH", "0"))
             g = self._graphs.get(key)
             if g is None:
                 for old in self._graphs.values():
@@ -475,6 +498,11 @@ class DDIMSampler:
         elif fp_u is not None:
             e_c = forward_sharded(c, 0)
             e_u = forward_sharded(uc, 1) if use_cfg else None
+        elif (use_cfg and os.environ.get("PANDORA_CFG_BATCH", "0") == "1" and isinstance(c, dict) and set(c) == set(uc)
+              and x.shape[0] == 1 and getattr(ops, "supports_batched_clips", True)):
+            cc = {k: [torch.cat([a, b_], 0) for a, b_ in zip(c[k], uc[k])] for k in c}
+            out = self.model.apply_model(torch.cat([x, x], 0), torch.cat([t, t], 0), cc, fs=fs, **kwargs)
+            e_c, e_u = out[0:1], out[1:2]
         else:
             e_c = self.model.apply_model(x, t, c, fs=fs, **kwargs)
             e_u = self.model.apply_model(x, t, uc, fs=fs, **kwargs) if use_cfg else None

@@ -1,0 +1,54 @@
+"""CPU (oracle op table): the cond / uncond pair of a CFG step as ONE U-Net forward over 2 x 16 frames (clips batched along
+the rows, UNetModel._forward with b = 2; PANDORA_CFG_BATCH=1 in the sampler) equals the two separate forwards the reference
+runs back to back (ddim.py:233-234) - per-frame ops see 32 frames, the frame-coupling ops ((T,H,W) GroupNorm, temporal conv,
+temporal attention) and the cross-attention keep the clips apart."""
+import pytest
+import torch
+
+from oracle import golden_recipe as gr
+from oracle.ops_torch import TorchOps
+from open_pandora_amd import synth
+from open_pandora_amd.ddim import DDIMSampler
+from open_pandora_amd.ddpm import LatentVisualDiffusion
+from open_pandora_amd.unet import UNetModel
+from test_oracle_golden import RH_KW, load, rel
+
+
+def _model():
+    torch.set_num_threads(8)
+    m = UNetModel(**dict(RH_KW, model_channels=64)).eval()
+    m.load_state_dict(synth.synth_state_dict(m, seed=gr.WEIGHT_SEED))
+    return m.bind(TorchOps())
+
+
+@pytest.mark.parametrize("L", [None, 77, 82], ids=["per_frame_image_tokens", "text_only", "shared_image_tokens"])
+def test_batched_forward_equals_two_forwards(L):
+    m = _model()
+    ins, _, _ = gr.sampler_inputs(8, 8)
+    x = torch.cat([ins["x_T"], ins["c_concat"]], 1)
+    t, fs = torch.tensor([500]), torch.tensor([15])
+    ca, cb = ins["c_crossattn"][:, :L], ins["uc_crossattn"][:, :L]
+    ya, yb = m(x, t, context=ca, fs=fs), m(x, t, context=cb, fs=fs)
+    y2 = m(torch.cat([x, x], 0), torch.cat([t, t]), context=torch.cat([ca, cb], 0), fs=fs)
+    assert y2.shape == (2, 4, 16, 8, 8)
+    assert rel(y2[0:1], ya) < 1e-5 and rel(y2[1:2], yb) < 1e-5 and rel(ya, yb) > 0.1
+    if L is None:
+        assert rel(ya, load("unet_small.npz")["mc64_8x8_t500"]) < 2e-5  # (and it is still the reference's forward)
+    with pytest.raises(NotImplementedError):
+        m(torch.cat([x, x], 0), torch.tensor([500, 499]), context=torch.cat([ca, cb], 0), fs=fs)
+
+
+def test_sampler_in_batch_mode_equals_the_reference_trajectory(monkeypatch):
+    S, eta, cfg = 5, 0.0, 4.0
+    g = load("ddim_small.npz")[f"S{S}_eta{eta:g}_cfg{cfg:g}"]
+    pm = LatentVisualDiffusion(_model())
+    ins, cond, uc = gr.sampler_inputs(8, 8)
+    shapes = []
+    inner = pm.apply_model
+    pm.apply_model = lambda x, t, c, **kw: (shapes.append(tuple(x.shape)), inner(x, t, c, **kw))[1]
+    monkeypatch.setenv("PANDORA_CFG_BATCH", "1")
+    y, _ = DDIMSampler(pm).sample(S=S, batch_size=1, shape=(4, 16, 8, 8), conditioning=cond, verbose=False,
+                                  unconditional_guidance_scale=cfg, unconditional_conditioning=uc, eta=eta,
+                                  fs=torch.tensor([15]), timestep_spacing="uniform_trailing", x_T=ins["x_T"])
+    assert shapes == [(2, 4, 16, 8, 8)] * S  # ONE forward per step
+    assert rel(y, g) < 5e-5

@@ -651,7 +651,7 @@ def _attn_ref_base2(q, k, v, heads):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("variant", [0, 3, 5, 16])
+@pytest.mark.parametrize("variant", [0, 3, 5, 16, 17])
 def test_attention_stale_max_paths(hip_ops_factory, dtype, variant):
     """attn_self_kernel keeps a STALE running maximum that is only raised when a tile outgrows it by 2^6: force
     every branch (cdna guide rule 26) - a raise in a fast (unmasked, not first) tile, twice for the same row; a

@@ -89,6 +89,40 @@ def test_ddim_small_trajectory(hip_ops_factory, dtype, S, eta, cfg):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_batched_clips_forward_and_sampler(hip_ops_factory, dtype, monkeypatch):
+    """VERDICT r03 #4a: the cond / uncond pair of a CFG step as ONE forward over 2 x 16 frames (clips batched along the rows:
+    weights read once, grids twice as full).  On the kernels: the batched forward against the two separate forwards (same
+    kernels, other split-K / tile plans at twice the rows: equal to rounding) and against the reference fixture; the sampler in
+    batch mode (PANDORA_CFG_BATCH=1: one graph, one stream) against the reference trajectory."""
+    tag, mc, h, w, t, fs = gr.UNET_SMALL_CASES[0]
+    m = small_model(mc, hip_ops_factory(dtype))
+    ins, cond, uc = gr.sampler_inputs(h, w)
+    x = torch.cat([ins["x_T"], ins["c_concat"]], 1).cuda()
+    ts, fsd = torch.tensor([t]).cuda(), torch.tensor([fs]).cuda()
+    ca, cb = ins["c_crossattn"].cuda(), ins["uc_crossattn"].cuda()
+    ya, yb = m(x, ts, context=ca, fs=fsd), m(x, ts, context=cb, fs=fsd)
+    y2 = m(torch.cat([x, x], 0), torch.cat([ts, ts]), context=torch.cat([ca, cb], 0), fs=fsd)
+    e_a, e_b = rel(y2[0:1].cpu(), ya.cpu()), rel(y2[1:2].cpu(), yb.cpu())
+    e_ref = rel(y2[0:1].cpu(), load("unet_small.npz")[tag])
+    print(f"\n[parity] batched clips {dtype}: batched vs separate forwards {e_a:.2e} / {e_b:.2e}; batched vs reference {e_ref:.2e}")
+    assert e_ref <= FWD_TOL_REDUCED[dtype] and max(e_a, e_b) <= 1.5 * FWD_TOL_REDUCED[dtype]
+    S, eta, cfg = 5, 0.0, 4.0
+    g = load("ddim_small.npz")[f"S{S}_eta{eta:g}_cfg{cfg:g}"]
+    pm = LatentVisualDiffusion(m)
+    dev = lambda c: {k: [v.cuda() for v in lst] for k, lst in c.items()}
+    monkeypatch.setenv("PANDORA_CFG_BATCH", "1")
+    smp = DDIMSampler(pm)
+    y, _ = smp.sample(S=S, batch_size=1, shape=(4, 16, 8, 8), conditioning=dev(cond), verbose=False,
+                      unconditional_guidance_scale=cfg, unconditional_conditioning=dev(uc), eta=eta,
+                      fs=torch.tensor([15]).cuda(), timestep_spacing="uniform_trailing", x_T=ins["x_T"].cuda())
+    graphs = list(smp._graphs.values())
+    assert len(graphs) == 1 and graphs[0].batched
+    err = rel(y.cpu(), g)
+    print(f"\n[parity] ddim_small S={S} cfg={cfg} {dtype}, CFG pair batched into one forward: rel err {err:.2e}")
+    assert err <= TRAJ_TOL_REDUCED[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("S,eta,cfg,cfg_img,gres", gr.DDIM_MULTICOND_CASES)
 def test_ddim_multicond_trajectory(hip_ops_factory, dtype, S, eta, cfg, cfg_img, gres):
     """the multi-condition sampler (three U-Net forwards per step replayed as ONE HIP graph, the text-on-

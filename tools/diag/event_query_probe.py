@@ -43,8 +43,14 @@ for name, rec_stream in (("event recorded on the stream that later captures", si
     torch.cuda.synchronize()
     before = query_from_thread(ev)
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-        x.add_(1.0)
-        during = query_from_thread(ev)
+    during, capture = {}, "capture completed"
+    try:
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+            x.add_(1.0)
+            during = query_from_thread(ev)
+    except Exception as exc:  # noqa: BLE001 - the query from the other thread can also invalidate the capture itself
+        capture = "capture FAILED: " + str(exc).splitlines()[0]
+    torch.cuda.synchronize()
     after = query_from_thread(ev)
-    print(f"{name}: query before capture {before} | DURING the capture of `side` {during} | after {after}")
+    print(f"{name}:\n   query before the capture {before}\n   query from a second thread DURING a thread-local capture of `side` {during}"
+          f"\n   {capture}\n   query after {after}", flush=True)
