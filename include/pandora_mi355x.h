@@ -151,6 +151,14 @@ int pm_conv_temporal_k3(const void* x, int64_t ldx, const void* halo_lo, const v
                         void* y, int64_t ldy, int64_t F, int64_t P, int64_t Cin, int64_t Cout,
                         const void* zero_page, int flags, int dtype, void* workspace,
                   size_t workspace_bytes, float* colstats, void* stream);
+/* The same over F / clip_frames independent clips batched along the frame axis (the cond / uncond pair of a CFG step as one
+ * U-Net forward, ddim.py:233-234): frame f reads f-1 / f+1 only inside its own clip, zero padding at both ends of every
+ * clip.  clip_frames divides F; halo frames only with clip_frames == F (pm_conv_temporal_k3 == this with clip_frames = F). */
+int pm_conv_temporal_k3_clips(const void* x, int64_t ldx, const void* halo_lo, const void* halo_hi,
+                              const void* Wp, const float* bias, const void* residual, int64_t ldr,
+                              void* y, int64_t ldy, int64_t F, int64_t clip_frames, int64_t P, int64_t Cin,
+                              int64_t Cout, const void* zero_page, int flags, int dtype, void* workspace,
+                              size_t workspace_bytes, float* colstats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm(32 groups) on channels-last data, optional fused SiLU.

@@ -15,7 +15,7 @@ extern "C" {
 
 /* Overrides which kernel variant pm_attention / pm_attention_fp8 launch for single-segment calls: 0 = the production
  * kernel (initial value, unless PANDORA_ATTN_VARIANT is set: read once, on first use), 3 / 5 / 9 = older variants kept
- * for A/B runs, 16 = the 16x16x32-MFMA form, 11 / 12 / 13 = ceiling probes of the production kernel whose OUTPUT IS NOT AN
+ * for A/B runs, 1 / 16 = force the 32x32x16 / the 16x16x32-MFMA production form at any length, 11 / 12 / 13 = ceiling probes of the production kernel whose OUTPUT IS NOT AN
  * ATTENTION RESULT (no global traffic / no softmax / no LDS reads: csrc/attn.hip).  Process-wide, not thread-safe:
  * measurement runs only. */
 void pm_debug_attn_variant(int variant);

@@ -230,7 +230,8 @@ class AutoencoderKL(packing.PackedWeights, nn.Module):
         C = x.shape[1]
         h = ops.groupnorm(x, *W["n"], 1e-6, F, False)
         q, k = ops.gemm(h, *W["q"]), ops.gemm(h, *W["k"])
-        h = h[:, :C]  # (parity op table: the norm output is [hi | lo]; V^T below takes it as the W operand: hi only)
+        if h.shape[1] != C:  # parity op table: the norm output is [hi | lo]; V^T below takes it as the (contiguous) W operand: hi only
+            h = h[:, :C].contiguous()
         out = ops.empty(F * P, C)
         for f in range(F):  # one single-head (h*w x h*w) attention per frame
             sl = slice(f * P, (f + 1) * P)

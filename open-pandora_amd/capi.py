@@ -36,6 +36,9 @@ SIGNATURES = {
     "pm_conv_temporal_k3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                     c_int64, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "pm_conv_temporal_k3_clips": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                          c_int64, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "pm_groupnorm_nchunks": (c_int64, [c_int64, c_int64]),
     "pm_groupnorm_stats": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                    c_int, c_int, c_void_p]),

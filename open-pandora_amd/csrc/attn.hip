@@ -1137,8 +1137,7 @@ extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const voi
                                        (hipStream_t)stream, p);                                                    \
                     return check_launch())
 #ifdef PM_DIAG
-  if (variant == 16 || variant == 17)  // the 16x16x32-MFMA form (attn16.hip) at 3 / 4 waves per SIMD
-    return launch_attn_self16(p, dtype, grid, (hipStream_t)stream, variant == 17 ? 4 : 3);
+  if (variant == 16) return launch_attn_self16(p, dtype, grid, (hipStream_t)stream);  // force the 16x16x32-MFMA form (attn16.hip)
   if (variant == 9)  // (kept for A/B runs: the round-1 kernel)
     PM_DISPATCH_DTYPE(dtype, T,
                       hipLaunchKernelGGL((attn_kernel<T, 1, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -1156,7 +1155,11 @@ extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const voi
     PM_ATTN_PROBE(3);
 #undef PM_ATTN_PROBE
   }
+  if (variant == 1) PM_ATTN_LAUNCH(1, false, false, 2);  // force the 32x32x16 form
 #endif
+  // long sequences: the 16x16x32-MFMA form (csrc/attn16.hip: +1-2 % by wall at N >= 2304 - the chip holds a ~11 % higher clock
+  // under that shape, profiles/r04/attention_shapes.txt); shorter ones: the 32x32x16 form (fewer, longer MFMAs per tile)
+  if (Nq >= 2048 && Nk1 >= 2048) return launch_attn_self16(p, dtype, grid, (hipStream_t)stream);
   PM_ATTN_LAUNCH(1, false, false, 2);
 #undef PM_ATTN_LAUNCH
 }

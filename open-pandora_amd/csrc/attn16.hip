@@ -2,6 +2,10 @@
 // per-wave output tile as attn_self_kernel<T, 1, ...> of attn.hip - 32 query rows x 64 keys per tile and wave - so that
 // the two shapes can be ranked by wall time and by the clock the chip holds under each, MI355X_MICROARCH.md "DVFS
 // give-back" item 7 / cdna_hip_programming.md rule 28).  Reference call site: CrossAttention.forward, attention.py:81-144.
+// Measured (profiles/r04/attention_shapes.txt, interleaved, random data, in-kernel clock stamps): this shape holds
+// 1.87-1.90 GHz where the 32x32x16 form holds 1.69 (+11 %) and spends ~9 % more cycles (an MFMA holds the SIMD's vector
+// issue for 8 of its 16 cycles instead of 8 of 32, and the softmax's vector work is the same): +2 % by wall at N = 9216,
+// +1 % at 2304, equal at 2560, slower below ~600 tokens -> pm_attention runs it for sequences of >= 2048 tokens.
 //
 // Same algorithm as attn_self_kernel (flash-style, base-2 scores, the running maximum subtracted BY the MFMA - the S
 // chain starts from a register block holding -m - and a STALE maximum raised only when a tile outgrows it by 2^6), other
@@ -31,9 +35,9 @@ __device__ __forceinline__ float xor16(float v) { return __shfl_xor(v, 16, 64); 
 // An inline-asm v_add_f32 is NOT the way to keep them single: hipcc inserts no wait state between a transcendental result
 // (v_exp_f32) and an asm statement that reads it - gfx950's trans-forwarding hazard - and the sums come out wrong.)
 
-// WPS: waves per SIMD the register allocation is held to (3: <= 168 VGPRs, 4: <= 128 - one more workgroup per CU)
-template <typename T, int WPS>
-__global__ __launch_bounds__(256, WPS) void attn_self16_kernel(const AttnParams p) {
+// (120 VGPRs, 32 KiB of LDS: four workgroups = 4 waves per SIMD are resident per CU)
+template <typename T>
+__global__ __launch_bounds__(256, 4) void attn_self16_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE_BYTES];  // K[2], V[2]
   char* const Ks = smem;
   char* const Vs = smem + 2 * KV_TILE_BYTES;
@@ -277,11 +281,8 @@ __global__ __launch_bounds__(256, WPS) void attn_self16_kernel(const AttnParams 
 
 // launcher used by pm_attention (attn.hip)
 namespace pm {
-int launch_attn_self16(const AttnParams& p, int dtype, dim3 grid, hipStream_t stream, int waves_per_simd) {
-  if (waves_per_simd == 4)
-    PM_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_self16_kernel<T, 4>), grid, dim3(256), 0, stream, p);
-                      return check_launch());
-  PM_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_self16_kernel<T, 3>), grid, dim3(256), 0, stream, p);
+int launch_attn_self16(const AttnParams& p, int dtype, dim3 grid, hipStream_t stream) {
+  PM_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_self16_kernel<T>), grid, dim3(256), 0, stream, p);
                     return check_launch());
 }
 }  // namespace pm

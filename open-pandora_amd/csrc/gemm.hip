@@ -130,9 +130,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         const int f = m / p.P;
         const int pix = m - f * p.P;
         a_off[j] = (uint32_t)((((int64_t)f * p.P + pix) * p.lda + lc * 8) * ES);
-        a_y[j] = f;
+        const int fc = f % p.Fc;  // frame inside its clip (Fc == F unless clips are batched along the rows)
+        a_y[j] = fc;
         a_x[j] = (int)(uint32_t)(((int64_t)pix * p.lda + lc * 8) * ES);  // byte offset of this row inside a halo frame
-        inv[j] = (f == 0 ? 1u : 0u) | (f == p.F - 1 ? 4u : 0u);  // taps reaching frame -1 / frame F
+        inv[j] = (fc == 0 ? 1u : 0u) | (fc == p.Fc - 1 ? 4u : 0u);  // taps reaching frame -1 / frame Fc of the clip
       }
     }
     if (AMODE == A_CONV3X3_FAST) {  // channel-chunk-major walk: K-tile s = (chunk s / 9, tap s % 9), see load_tile
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         const int sf = a_y[j] + tap_s - 1;
         src = ab + a_off[j];
         if (sf < 0) src = hlo ? hlo + (uint32_t)a_x[j] : zero;
-        if (sf >= p.F) src = hhi ? hhi + (uint32_t)a_x[j] : zero;
+        if (sf >= p.Fc) src = hhi ? hhi + (uint32_t)a_x[j] : zero;
       } else {
         int iy = a_y[j] + dy - 1, ix = a_x[j] + dx - 1;
         const bool ok = kin_l && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv;
@@ -491,9 +492,10 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
           const int f = m / p.P;
           const int pix = m - f * p.P;
           a_off[j] = (uint32_t)((((int64_t)f * p.P + pix) * p.lda + lc * 8) * 2);
-          a_y[j] = f;
+          const int fc = f % p.Fc;  // frame inside its clip (Fc == F unless clips are batched along the rows)
+          a_y[j] = fc;
           a_x[j] = (int)(uint32_t)(((int64_t)pix * p.lda + lc * 8) * 2);  // byte offset inside a halo frame
-          inv[j] = (f == 0 ? 1u : 0u) | (f == p.F - 1 ? 4u : 0u);  // taps reaching frame -1 / frame F
+          inv[j] = (fc == 0 ? 1u : 0u) | (fc == p.Fc - 1 ? 4u : 0u);  // taps reaching frame -1 / frame Fc of the clip
         }
       }
       if (AMODE == A_CONV3X3_FAST) {  // channel-chunk-major walk (see gemm_kernel's load_tile)
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
             const int sf = a_y[j] + tap_s - 1;
             src = ab + a_off[j];
             if (sf < 0) src = hlo ? hlo + (uint32_t)a_x[j] : zero;
-            if (sf >= p.F) src = hhi ? hhi + (uint32_t)a_x[j] : zero;
+            if (sf >= p.Fc) src = hhi ? hhi + (uint32_t)a_x[j] : zero;
           }
           const int dst = buf * STAGE_BYTES + (32 * j + 8 * lw) * 128;
           __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(As + dst), 16, 0, 0);
@@ -883,9 +885,10 @@ __global__ __launch_bounds__(512, 1) void gemm_ringw_kernel(const GemmParams p) 
           const int f = m / p.P;
           const int pix = m - f * p.P;
           a_off[j] = (uint32_t)((((int64_t)f * p.P + pix) * p.lda + lc * 8) * 2);
-          a_y[j] = f;
+          const int fc = f % p.Fc;  // frame inside its clip (Fc == F unless clips are batched along the rows)
+          a_y[j] = fc;
           a_x[j] = (int)(uint32_t)(((int64_t)pix * p.lda + lc * 8) * 2);  // byte offset inside a halo frame
-          inv[j] = (f == 0 ? 1u : 0u) | (f == p.F - 1 ? 4u : 0u);  // taps reaching frame -1 / frame F
+          inv[j] = (fc == 0 ? 1u : 0u) | (fc == p.Fc - 1 ? 4u : 0u);  // taps reaching frame -1 / frame Fc of the clip
         }
       }
       if (AMODE == A_CONV3X3_FAST) {  // channel-chunk-major walk (see gemm_kernel's load_tile)
@@ -954,7 +957,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ringw_kernel(const GemmParams p) 
             const int sf = a_y[j] + tap_s - 1;
             src = ab + a_off[j];
             if (sf < 0) src = hlo ? hlo + (uint32_t)a_x[j] : zero;
-            if (sf >= p.F) src = hhi ? hhi + (uint32_t)a_x[j] : zero;
+            if (sf >= p.Fc) src = hhi ? hhi + (uint32_t)a_x[j] : zero;
           }
           const int dst = buf * STAGE_BYTES + (32 * j + 8 * lw) * 128;
           __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(As + dst), 16, 0, 0);
@@ -1612,7 +1615,19 @@ extern "C" int pm_conv_temporal_k3(const void* x, int64_t ldx, const void* halo_
                                    int64_t F, int64_t P, int64_t Cin, int64_t Cout,
                                    const void* zero_page, int flags, int dtype, void* workspace,
                                    size_t workspace_bytes, float* colstats, void* stream) {
+  return pm_conv_temporal_k3_clips(x, ldx, halo_lo, halo_hi, Wp, bias, residual, ldr, y, ldy, F, F, P, Cin, Cout, zero_page,
+                                   flags, dtype, workspace, workspace_bytes, colstats, stream);
+}
+
+extern "C" int pm_conv_temporal_k3_clips(const void* x, int64_t ldx, const void* halo_lo,
+                                         const void* halo_hi, const void* Wp, const float* bias,
+                                         const void* residual, int64_t ldr, void* y, int64_t ldy,
+                                         int64_t F, int64_t clip_frames, int64_t P, int64_t Cin, int64_t Cout,
+                                         const void* zero_page, int flags, int dtype, void* workspace,
+                                         size_t workspace_bytes, float* colstats, void* stream) {
   if (!zero_page) return PM_E_NULL;
+  if (clip_frames < 1 || F % clip_frames) return PM_E_SHAPE;
+  if (clip_frames != F && (halo_lo || halo_hi)) return PM_E_SHAPE;  // (halo frames belong to ONE clip's ends)
   if ((Cin & 7) || (ldx & ((flags & PM_FLAG_A_F32) ? 3 : 7)) || ldx < Cin) return PM_E_SHAPE;
   if (Cin % BK) return PM_E_SHAPE;  // one tap per K-tile
   if (!fits_u32(F * P * ldx, flags)) return PM_E_SHAPE;
@@ -1626,7 +1641,7 @@ extern "C" int pm_conv_temporal_k3(const void* x, int64_t ldx, const void* halo_
   p.res32 = (flags & (PM_FLAG_OUT_F32 | PM_FLAG_RES_F32)) ? 1 : 0;
   p.colstats = colstats;
   p.ntiles = (int)((Cout + BN - 1) / BN);
-  p.Cin = (int)Cin; p.F = (int)F; p.P = (int)P; p.halo_lo = halo_lo; p.halo_hi = halo_hi;
+  p.Cin = (int)Cin; p.F = (int)F; p.Fc = (int)clip_frames; p.P = (int)P; p.halo_lo = halo_lo; p.halo_hi = halo_hi;
   p.zero = zero_page;
   p.a_bytes = ((F * P - 1) * ldx + Cin) * ((flags & PM_FLAG_A_F32) ? 4 : 2);
   for (int t = 0; t < 3; ++t) {

@@ -32,8 +32,8 @@ struct GemmParams {
   float* colstats;   // optional [ceil(M/64)][Nout][2]: column {sum, sum of squares} of every 64 output rows
   // conv3x3
   int Hin, Win, Hv, Wv, Cin, Ho, Wo, stride, ups, pad;  // pad: zero rows/cols before the image (1, or 0)
-  // temporal conv
-  int F, P;
+  // temporal conv: F frames of P pixels; clips of Fc frames (Fc divides F) are independent: zero padding at BOTH ends of each
+  int F, P, Fc;
   const void* halo_lo;
   const void* halo_hi;
   const void* zero;

@@ -23,6 +23,7 @@ def _ptr(t):
 class HipOps:
     name = "hip"
     supports_graphs = True  # every op only enqueues kernels on the current stream: capturable
+    conv_t3_clips = True    # conv_t3(clip_frames=...): independent clips batched along the frame axis in one launch
     # pm_attention's single-segment kernel works in the base-2 domain on q * (64^-1/2 * log2 e).  A caller that
     # owns the q projection folds this factor into its weights (UNetModel.prepare) and calls
     # attention(..., prescaled=True); otherwise the kernel scales (and re-rounds) the q fragments itself.
@@ -249,8 +250,9 @@ class HipOps:
         return self._stats_end(out, col, stats)
 
     def conv_t3(self, x, wp, bias, F, P, residual=None, halo_lo=None, halo_hi=None, out=None, stream=False,
-                stats=None):
-        """3-tap conv over frames: x [F*P, Cin] -> [F*P, Cout]; wp packed [Cout, 3*Cin]."""
+                stats=None, clip_frames=None):
+        """3-tap conv over frames: x [F*P, Cin] -> [F*P, Cout]; wp packed [Cout, 3*Cin].
+        clip_frames: F / clip_frames independent clips batched along the frames (zero padding at both ends of each)."""
         if x.dtype == torch.float32 and self.presplit and halo_lo is None and halo_hi is None and x.shape[1] % 8 == 0:
             x = self.split16(x)
         if x.shape[1] * 3 == 2 * wp.shape[1]:
@@ -262,12 +264,12 @@ class HipOps:
             assert h is None or (h.shape == (P, cin) and self._rows(h) == self._rows(x))
         flags, out = self._gemm_io(x, residual, out, F * P, cout, stream)
         col = self._stats_begin(F * P, cout, stats, 3 * cin)
-        rc = self.lib.pm_conv_temporal_k3(_ptr(x), self._rows(x, True), _ptr(halo_lo), _ptr(halo_hi),
-                                          _ptr(wp), _ptr(bias), _ptr(residual),
-                                          residual.stride(0) if residual is not None else 0,
-                                          _ptr(out), out.stride(0), F, P, cin, cout,
-                                          _ptr(self.zero_page), flags, self.dt, _ptr(self.workspace),
-                                          self.ws_bytes, _ptr(col[0] if col else None), self._stream())
+        rc = self.lib.pm_conv_temporal_k3_clips(_ptr(x), self._rows(x, True), _ptr(halo_lo), _ptr(halo_hi),
+                                                _ptr(wp), _ptr(bias), _ptr(residual),
+                                                residual.stride(0) if residual is not None else 0,
+                                                _ptr(out), out.stride(0), F, clip_frames or F, P, cin, cout,
+                                                _ptr(self.zero_page), flags, self.dt, _ptr(self.workspace),
+                                                self.ws_bytes, _ptr(col[0] if col else None), self._stream())
         capi.check(rc, f"pm_conv_temporal_k3 F={F} P={P} Cin={cin} Cout={cout}")
         return self._stats_end(out, col, stats)
 

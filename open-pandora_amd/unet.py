@@ -446,12 +446,16 @@ class UNetModel(packing.PackedWeights, nn.Module):
     @staticmethod
     def _conv_t3(c, t, wp, b, P, residual=None, halo_lo=None, halo_hi=None, stats=None, out=None):
         """The 3-tap conv over frames of every clip (zero padding at BOTH ends of each clip, openaimodel3d.py:258-269 on
-        `(b c t h w)`): one launch per clip on its row block - the taps must not reach into the neighbouring clip.
+        `(b c t h w)`): the taps must not reach into the neighbouring clip - one clip-aware launch (pm_conv_temporal_k3_clips)
+        or, on op tables without it, one launch per clip on its row block.
         `stats` counts instances PER CLIP; totals of the clips are stacked.  -> (out f32 [F*P, Cout], totals or None)."""
         ops = c.ops
         if c.B == 1:
             return ops.conv_t3(t, wp, b, c.F, P, residual=residual, halo_lo=halo_lo, halo_hi=halo_hi, stream=True,
                                stats=stats, out=out)
+        if getattr(ops, "conv_t3_clips", False):  # ONE launch: the kernel keeps the taps inside each clip
+            st = None if stats is None else (stats[0] * c.B,) + tuple(stats[1:])
+            return ops.conv_t3(t, wp, b, c.F, P, residual=residual, stream=True, stats=st, out=out, clip_frames=c.T)
         rows = c.T * P
         if out is None:
             out = torch.empty(c.F * P, wp.shape[0], dtype=torch.float32, device=t.device)
@@ -637,7 +641,9 @@ class UNetModel(packing.PackedWeights, nn.Module):
         c.kv_text = ops.gemm(c.ctx_text, c.w["kv_text_all"]) if c.w["kv_text_all"] is not None else None
         c.kv_img = (ops.gemm(c.ctx_img, c.w["kv_img_all"])
                     if c.w["kv_img_all"] is not None and c.ctx_img is not None else None)
-        if b > 1 and timesteps.numel() > 1 and not bool((timesteps == timesteps.reshape(-1)[0]).all()):
+        # batched clips share ONE timestep (the CFG pair of a DDIM step): checked where that costs nothing - a host tensor;
+        # a device tensor would need a synchronising read, which is illegal inside the sampler's graph capture
+        if b > 1 and timesteps.numel() > 1 and not timesteps.is_cuda and not bool((timesteps == timesteps.reshape(-1)[0]).all()):
             raise NotImplementedError("batched clips share one timestep (the CFG pair of a DDIM step)")
         c.emb_bias = self._embed(c, timesteps, fs)
 

@@ -390,6 +390,33 @@ def test_attention_self_fused_qkv(hip_ops_factory, dtype, B, heads, N):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("prescaled", [False, True])
+def test_attention_long_sequences_16x16x32_form(hip_ops_factory, dtype, prescaled):
+    """Sequences of >= 2048 tokens run on attn_self16_kernel (csrc/attn16.hip, v_mfma_f32_16x16x32: two query rows per lane,
+    the P^T operand built from the S accumulators of two 16-key blocks, V^T through paired transposed reads 16 keys apart)
+    in the SHIPPED library: ragged length (masked last tile, query tile not full), a raise of the stale maximum in a fast
+    tile (twice for one row) and in the ragged last tile, a dominant key in the first tile, both scaling modes."""
+    ops = hip_ops_factory(dtype)
+    B, heads, N = 2, 3, 2100  # 32 whole key tiles + 52 keys; 16 whole query tiles + 52 rows
+    C = heads * 64
+    q = rnd(B, N, C, dtype=torch.float32, scale=0.3 if prescaled else 1.0, seed=1)
+    k = rnd(B, N, C, dtype=torch.float32, seed=2)
+    v = rnd(B, N, C, dtype=torch.float32, seed=3)
+    amp = (lambda a: 2.0 * a) if prescaled else (lambda a: a)  # (similar base-2 score magnitudes in both modes)
+    k[0, 70] = amp(3 * q[0, 5])
+    k[0, 1300] = amp(6 * q[0, 5])
+    k[1, 2099] = amp(5 * q[1, 2080])
+    k[1, 10] = amp(8 * q[1, 300])
+    k[0, 2060] = amp(4 * q[0, 2090])
+    q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
+    want = _attn_ref_base2(q, k, v, heads) if prescaled else REF.attention(q, k, v, heads)
+    got = ops.attention(q.cuda(), k.cuda(), v.cuda(), heads, prescaled=prescaled)
+    assert rel_err(got, want) <= TOL[dtype]
+    for (b, i) in ((0, 5), (1, 2080), (1, 300), (0, 2090), (0, 6), (1, 2099)):
+        assert rel_err(got[b, i], want[b, i]) <= 2 * TOL[dtype], (b, i)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_peaked_scores(hip_ops_factory, dtype):
     """Force the running max to jump late: one key in the LAST tile dominates a few query rows."""
     ops = hip_ops_factory(dtype)
@@ -651,13 +678,13 @@ def _attn_ref_base2(q, k, v, heads):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("variant", [0, 3, 5, 16, 17])
+@pytest.mark.parametrize("variant", [0, 1, 3, 5, 16])
 def test_attention_stale_max_paths(hip_ops_factory, dtype, variant):
     """attn_self_kernel keeps a STALE running maximum that is only raised when a tile outgrows it by 2^6: force
     every branch (cdna guide rule 26) - a raise in a fast (unmasked, not first) tile, twice for the same row; a
     raise in the last fast tile; rows whose scores stay far BELOW the first tile's maximum; a ragged masked
     last tile; rows that never raise - in all kernel variants (32 / 64 rows per wave, pipelined P.V; 16 = the 16x16x32-MFMA
-    form, csrc/attn16.hip)."""
+    form, csrc/attn16.hip; 0 = the shipped library's own choice, 1 / 16 force the two production forms)."""
     # (variant 0 = the shipped library; the other variants exist only in the diagnostics build, include/pandora_mi355x_diag.h)
     ops = hip_ops_factory(dtype) if variant == 0 else hip_ops_factory(dtype, diag=True)
     B, heads = 2, 3

@@ -1,5 +1,5 @@
 """The two bf16 MFMA shapes of the spatial self-attention at the SAME per-wave output tile (cdna guide
-rule 28): variant 0 = attn_self_kernel on v_mfma_f32_32x32x16, variant 16 = attn_self16_kernel on v_mfma_f32_16x16x32
+rule 28): variant 1 = attn_self_kernel on v_mfma_f32_32x32x16, variant 16 = attn_self16_kernel on v_mfma_f32_16x16x32
 (csrc/attn16.hip).  Interleaved rounds in ONE process on random data; per variant: wall time / TFLOP/s AND the in-kernel
 clock the chip holds under it (d s_memtime / d s_memrealtime x 100 MHz stamped around every workgroup's body by the
 DIAGNOSTICS build, after >= 2 s of back-to-back launches; median over workgroups), i.e. cycles AND wall.
@@ -19,7 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--rounds", type=int, default=7)
-    ap.add_argument("--variants", default="0,16,17")
+    ap.add_argument("--variants", default="1,16")
     ap.add_argument("--shapes", default="9216x5,2304x10,2560x5,640x10,576x20")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
@@ -83,7 +83,7 @@ def main():
             t = sorted(res[vv])
             med, mn = t[len(t) // 2], t[0]
             c = sorted(clk[vv])[1]
-            print(f"N={N:5d} heads={heads:2d} variant {vv:2d} ({'32x32x16, 3 waves/SIMD' if vv == 0 else '16x16x32, 3 waves/SIMD' if vv == 16 else '16x16x32, 4 waves/SIMD' if vv == 17 else 'other'}): "
+            print(f"N={N:5d} heads={heads:2d} variant {vv:2d} ({'32x32x16, 3 waves/SIMD' if vv == 1 else '16x16x32, 4 waves/SIMD' if vv == 16 else 'auto' if vv == 0 else 'other'}): "
                   f"median {med:.3f} ms ({fl / med / 1e9:7.1f} TF/s = {fl / med / 1e9 / 2500:.3f} of 2.5 PF)  "
                   f"min {mn:.3f} ms ({fl / mn / 1e9:7.1f} TF/s)  in-kernel clock {c[0]:.3f} GHz, "
                   f"{c[1] / 1e3:.1f} k cycles per workgroup")

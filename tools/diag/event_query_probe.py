@@ -16,7 +16,6 @@ import threading
 import torch
 
 dev = torch.device("cuda:0")
-side, other = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
 x = torch.zeros(1 << 20, device=dev)
 
 
@@ -34,8 +33,10 @@ def query_from_thread(ev):
     return out
 
 
-for name, rec_stream in (("event recorded on the stream that later captures", side),
-                         ("event recorded on another stream", other)):
+for name, same in (("event recorded on ANOTHER stream than the one that captures", False),
+                   ("event recorded on the stream that LATER captures", True)):
+    side, other = torch.cuda.Stream(dev), torch.cuda.Stream(dev)  # fresh streams per case (a failed capture poisons its stream)
+    rec_stream = side if same else other
     ev = torch.cuda.Event()
     with torch.cuda.stream(rec_stream):
         x.add_(1.0)
@@ -54,3 +55,7 @@ for name, rec_stream in (("event recorded on the stream that later captures", si
     after = query_from_thread(ev)
     print(f"{name}:\n   query before the capture {before}\n   query from a second thread DURING a thread-local capture of `side` {during}"
           f"\n   {capture}\n   query after {after}", flush=True)
+
+import os, sys  # noqa: E402,E401
+sys.stdout.flush()
+os._exit(0)  # (the CUDAGraph object of the failed capture cannot be destroyed cleanly: torch terminates in its destructor)
