@@ -20,7 +20,7 @@ objects:
                       clips of T/N frames for N = 2, 4, 8 - the compute-side bound of the N-GPU speed-up.
 `share_of_sequential_step` are shares of the EAGER, single-stream step the family times were taken in (they sum to 1 with
 `other`); the timed steps replay a two-stream graph and are shorter than that sum.  `roofline.traffic` comes from the
-committed PMC summary (profiles/r03/pmc_traffic.json, separate rocprofv3 --pmc passes) only when that file was
+committed PMC summary (profiles/r04/pmc_traffic.json, separate rocprofv3 --pmc passes) only when that file was
 produced with the library sources of this run (digest match), else null - never a stale constant.
 """
 import argparse
@@ -244,7 +244,7 @@ def committed_traffic(res, fam="gemm"):
     """HBM-side bytes per launch of a kernel family from the committed PMC summary (separate rocprofv3 --pmc passes over
     one eager forward, gfx950 FETCH_SIZE correction applied there: tools/pmc_traffic.py) - only when it was taken with
     the library sources of THIS run; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r04", "pmc_traffic.json")
     try:
         from open_pandora_amd import build as _b
         with open(path) as f:
@@ -275,8 +275,17 @@ def compute_scaling(pm_of, unet, ops, dev, reps=6):
             uc = {"c_crossattn": [ins["uc_crossattn"].to(dev)], "c_concat": [ins["c_concat"].to(dev)]}
             x, ts, fs = ins["x_T"].to(dev), torch.full((1,), 500, device=dev, dtype=torch.long), torch.tensor([15], device=dev)
             entry = {"frames": t}
-            for tag, u in (("one_forward_ms", None), ("cfg_pair_two_streams_ms", uc)):
-                g = _ForwardGraph(pm, x, ts, cond, u, fs, {})
+            for tag, u in (("one_forward_ms", None), ("cfg_pair_two_streams_ms", uc), ("cfg_pair_batched_ms", uc)):
+                # (batched: the pair as ONE forward over 2 x t frames, PANDORA_CFG_BATCH=1 - weights read once, grids twice as full)
+                prev = os.environ.get("PANDORA_CFG_BATCH")
+                os.environ["PANDORA_CFG_BATCH"] = "1" if tag == "cfg_pair_batched_ms" else "0"
+                try:
+                    g = _ForwardGraph(pm, x, ts, cond, u, fs, {})
+                finally:
+                    if prev is None:
+                        os.environ.pop("PANDORA_CFG_BATCH", None)
+                    else:
+                        os.environ["PANDORA_CFG_BATCH"] = prev
                 g(x, ts)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -290,10 +299,15 @@ def compute_scaling(pm_of, unet, ops, dev, reps=6):
         for n, e in row.items():
             e["speedup_one_forward"] = base1 / e["one_forward_ms"]
             e["speedup_cfg_pair"] = base2 / e["cfg_pair_two_streams_ms"]
+            e["speedup_cfg_pair_batched"] = row["1"]["cfg_pair_batched_ms"] / e["cfg_pair_batched_ms"]
         # the two 8-GPU decompositions of frame_parallel.make_hybrid, compute side only (1-GPU step = cfg pair on 16 frames)
+        for n, e in row.items():
+            e["cfg_pair_best_ms"] = min(e["cfg_pair_two_streams_ms"], e["cfg_pair_batched_ms"])
+        base2 = row["1"]["cfg_pair_best_ms"]  # (the 1-GPU step = the faster of the two forms on 16 frames)
         row["projection_8gpu"] = {
             "cfg_pair_x_4_frame_shards": base2 / row["4"]["one_forward_ms"],
             "8_frame_shards_both_branches_per_rank": base2 / row["8"]["cfg_pair_two_streams_ms"],
+            "8_frame_shards_both_branches_batched_per_rank": base2 / row["8"]["cfg_pair_batched_ms"],
             "note": "1-GPU step time / one rank's kernel time at its shard size: an upper bound, exchanges not included"}
         row["projection_4gpu"] = {"cfg_pair_x_2_frame_shards": base2 / row["2"]["one_forward_ms"]}
         row["projection_2gpu"] = {"cfg_pair": base2 / row["1"]["one_forward_ms"]}
@@ -332,7 +346,7 @@ def attention_ceiling(ops, dtype, rounds=3, reps=5):
             "production_kernel_same_tensors_tflops": fl / best[0] / 1e9,
             "production_over_ceiling": best[11] / best[0],
             "what": "the production kernel's per-tile instruction stream with K/V resident in LDS (no global traffic): "
-                    "profiles/r03/attention_ceiling.txt"}
+                    "profiles/r03/attention_ceiling.txt, profiles/r04/attention_shapes.txt"}
 
 
 def main():

@@ -98,13 +98,19 @@ def test_frames_full_width_320x512(hip_ops_factory, tag, S, eta, dtype):
 # carried as [hi | lo] 16-bit parts) in f16.  bench.py --parity --dtype f16 puts this configuration's step
 # time on record next to the bf16 production number.
 FRAMES_PARITY_TOL = 1e-3
+# A 2-step trajectory is NOT the north-star's configuration: its two forwards sit at t = 999 (zero terminal SNR: the model output
+# IS the sample) and t = 499 and enter the result with the full guidance amplification, nothing averages out (measured 1.5e-3 on
+# the latent, 1.7e-3 on frames, against 8.1e-4 / 9.4e-4 for 10 steps at 320x512).  It is kept as the cheap 576x1024 fixture
+# (937 s of reference CPU) with its own, stated bound; the 10-step 576x1024 fixture (~80 min of reference CPU) carries the 1e-3.
+FRAMES_PARITY_TOL_2STEP = 2.0e-3
 
 
-@pytest.mark.parametrize("res,h,w,S", [("320x512", 40, 64, 10), ("576x1024", 72, 128, 2)])
-def test_frames_full_width_parity_mode(res, h, w, S):
+@pytest.mark.parametrize("res,h,w,S,tol", [("320x512", 40, 64, 10, FRAMES_PARITY_TOL), ("576x1024", 72, 128, 10, FRAMES_PARITY_TOL),
+                                           ("576x1024", 72, 128, 2, FRAMES_PARITY_TOL_2STEP)])
+def test_frames_full_width_parity_mode(res, h, w, S, tol):
     """Full-width sampler -> first-stage decode in the parity configuration against the REAL reference's frames
     (DDIMSampler.sample -> decode_first_stage, ddim.py:66 / ddpm3d.py:630-655): BASELINE config 1 (320x512, 10 CFG-4 steps,
-    eta 0) and 576x1024 (configs[2]'s latent, 2 CFG-4 steps: one reference step is ~7 min of CPU at that size)."""
+    eta 0) and 576x1024 (configs[2]'s latent; 10 and 2 CFG-4 steps: one reference step is ~7 min of CPU at that size)."""
     path = os.path.join(GOLD, f"frames_full_{h}x{w}_s{S}_eta0.npz")
     if not os.path.exists(path):
         pytest.skip(f"{os.path.basename(path)} not generated yet (oracle/make_golden.py --frames-full[-72x128])")
@@ -123,7 +129,7 @@ def test_frames_full_width_parity_mode(res, h, w, S):
     e_f, std, gstd = _digest(frames, g, "frames")
     print(f"\n[parity] PARITY MODE frames full {res} S={S} eta=0 f16: latent {e_z:.2e} -> frames {e_f:.2e} "
           f"(std {std:.4f} vs {gstd:.4f})")
-    assert frames.shape == (1, 3, 16, 8 * h, 8 * w) and e_f <= FRAMES_PARITY_TOL
+    assert frames.shape == (1, 3, 16, 8 * h, 8 * w) and e_f <= tol
     del ae
     torch.cuda.empty_cache()
 

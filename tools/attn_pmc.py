@@ -13,7 +13,7 @@ ops = HipOps(torch.bfloat16, "cuda:0", diag=True)  # (variant overrides: the dia
 N, heads, F = (int(sys.argv[1]) if len(sys.argv) > 1 else 9216), 5, 16
 C = heads * 64
 qkv = torch.randn(F, N, 3 * C, device="cuda", dtype=torch.bfloat16)
-variants = (0,) if (len(sys.argv) > 2 and sys.argv[2] == "prod") else (9, 1, 3, 5)  # 0 = the production choice
+variants = (0,) if (len(sys.argv) > 2 and sys.argv[2] == "prod") else (1, 16, 3, 5)  # 0 = the production choice; 1 / 16 = the two MFMA shapes
 for vv in variants:
     ops.lib.pm_debug_attn_variant(vv)
     for _ in range(4):
