@@ -1157,9 +1157,9 @@ extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const voi
   }
   if (variant == 1) PM_ATTN_LAUNCH(1, false, false, 2);  // force the 32x32x16 form
 #endif
-  // long sequences: the 16x16x32-MFMA form (csrc/attn16.hip: +1-2 % by wall at N >= 2304 - the chip holds a ~11 % higher clock
+  // long sequences: the 16x16x32-MFMA form (csrc/attn16.hip: +1-2 % by wall at N = 9216, +-1 % around 2304-2560 - the chip holds a ~11 % higher clock
   // under that shape, profiles/r04/attention_shapes.txt); shorter ones: the 32x32x16 form (fewer, longer MFMAs per tile)
-  if (Nq >= 2048 && Nk1 >= 2048) return launch_attn_self16(p, dtype, grid, (hipStream_t)stream);
+  if (Nq >= 4096 && Nk1 >= 4096) return launch_attn_self16(p, dtype, grid, (hipStream_t)stream);
   PM_ATTN_LAUNCH(1, false, false, 2);
 #undef PM_ATTN_LAUNCH
 }

@@ -5,7 +5,7 @@
 // Measured (profiles/r04/attention_shapes.txt, interleaved, random data, in-kernel clock stamps): this shape holds
 // 1.87-1.90 GHz where the 32x32x16 form holds 1.69 (+11 %) and spends ~9 % more cycles (an MFMA holds the SIMD's vector
 // issue for 8 of its 16 cycles instead of 8 of 32, and the softmax's vector work is the same): +2 % by wall at N = 9216,
-// +1 % at 2304, equal at 2560, slower below ~600 tokens -> pm_attention runs it for sequences of >= 2048 tokens.
+// +-1 % at 2304 - 2560, slower below ~600 tokens -> pm_attention runs it for sequences of >= 4096 tokens.
 //
 // Same algorithm as attn_self_kernel (flash-style, base-2 scores, the running maximum subtracted BY the MFMA - the S
 // chain starts from a register block holding -m - and a STALE maximum raised only when a tile outgrows it by 2^6), other

@@ -63,6 +63,7 @@ class _ForwardGraph:
         image-only branch, ddim_multiplecond.py:232): captured on the main stream behind the conditional forward."""
         self.x = x.clone()
         self.t = t.clone()
+        self.cc = None
         dev = x.device
         side, other = _capture_streams(dev)
         # PANDORA_CFG_BATCH=1: the cond / uncond pair as ONE forward over 2 x T frames (UNetModel batches the clips along the
@@ -70,7 +71,9 @@ class _ForwardGraph:
         self.batched = (uc is not None and not extra and os.environ.get("PANDORA_CFG_BATCH", "0") == "1"
                         and isinstance(c, dict) and set(c) == set(uc) and x.shape[0] == 1)
         if self.batched:
-            cc = {k: [torch.cat([a, b_], 0) for a, b_ in zip(c[k], uc[k])] for k in c}  # (static copies: the graph reads these)
+            # static copies of the stacked conditions: the graph reads THESE at every replay, so they live as long as it does
+            # (kept on self: as locals they were freed at the end of __init__ and the next eager allocation overwrote them)
+            cc = self.cc = {k: [torch.cat([a, b_], 0) for a, b_ in zip(c[k], uc[k])] for k in c}
             self.x = torch.cat([x, x], 0)
             self.t = torch.cat([t, t], 0)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -128,7 +131,7 @@ class _ForwardGraph:
 
     def close(self):
         """Drop the graph and the outputs that live in its private pool (DDIMSampler.close)."""
-        self.graph = self.e_c = self.e_u = None
+        self.graph = self.e_c = self.e_u = self.cc = None
         self.e_x = []
 
 
