@@ -140,7 +140,7 @@ def test_frames_full_width_parity_mode(res, h, w, S, tol):
 # MFMA and leaves the deep levels, the cross-attentions and the temporal attentions on 16-bit operands.  Frames against the
 # REAL reference's 2-step fixture.  The bound is 1.3 x the measured value (printed): a regression of the selection rule or
 # of the fp8 kernel fails it - it is not a loose "cannot fail" number.
-FRAMES_FP8_576_TOL = 2.0e-2  # measured value: see the [parity] line / DESIGN.md section 3
+FRAMES_FP8_576_TOL = 1.1e-2  # measured 8.2e-3 (latent 7.4e-3); f16 without fp8: 2.3e-3 / parity mode 1.7e-3 on the same fixture
 
 
 def test_frames_full_width_576x1024_fp8_attention_selective():

@@ -145,9 +145,10 @@ def test_ddim_multicond_trajectory(hip_ops_factory, dtype, S, eta, cfg, cfg_img,
     graphs = list(smp._graphs.values())
     assert len(graphs) == 1 and len(graphs[0].e_x) == 1  # ONE graph holds all three forwards of a step
     print(f"\n[parity] ddim multi-condition S={S} eta={eta} cfg={cfg} cfg_img={cfg_img} gr={gres} {dtype}: rel err {err:.2e}")
-    # three forwards enter with weights (1 - cfg_img), (cfg_img - cfg), cfg: the guidance amplification of the two-way bound
-    # grows by |cfg_img - cfg| + |1 - cfg_img| - |1 - cfg| <= 2 cfg_img at these settings; measured values in DESIGN.md
-    assert err <= 2.0 * TRAJ_TOL_REDUCED[dtype]
+    # three forwards enter with weights (1 - cfg_img), (cfg_img - cfg), cfg; the second case runs 20 steps at scale 7.5 (the
+    # two-way bound assumes scale 4): 1.5 x the reduced-width trajectory tolerance.  Measured 2.5e-3 / 4.3e-3 (f16),
+    # 2.1e-2 / 3.5e-2 (bf16)
+    assert err <= 1.5 * TRAJ_TOL_REDUCED[dtype]
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
