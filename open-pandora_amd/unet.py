@@ -602,15 +602,13 @@ class UNetModel(packing.PackedWeights, nn.Module):
             # (packed, detached weights), so the graph is walked with differentiable torch ops over the module's own
             # parameters instead; inference - eval() or no_grad - never takes this branch
             from . import unet_train
-            _unsupported(features_adapter is not None, "features_adapter")
-            return unet_train.forward(self, x, timesteps, context, fs)
+            return unet_train.forward(self, x, timesteps, context, fs, features_adapter)
         with torch.no_grad():
             return self._forward(x, timesteps, context, features_adapter, fs, **kwargs)
 
     def _forward(self, x, timesteps, context=None, features_adapter=None, fs=None, **kwargs):
         if self.ops is None:
             raise RuntimeError("UNetModel.bind(ops) must be called before forward (no implicit CPU fallback)")
-        _unsupported(features_adapter is not None, "features_adapter")
         packed = self.packed()
         b, cin, t, hh, ww = x.shape
         # b > 1: clips batched along the rows - the sampler's cond / uncond pair of a CFG step as ONE forward over 2 x 16
@@ -670,7 +668,17 @@ class UNetModel(packing.PackedWeights, nn.Module):
             for si, sq in enumerate(seqs):
                 h = self._run(c, sq, h, buf[:, total - ch:] if si == len(seqs) - 1 else None)
             assert h.data_ptr() == buf[:, total - ch:].data_ptr() and (c.H, c.W) == (gh, gw)
+            if features_adapter is not None and (i + 1) % 3 == 0:
+                # plug-in adapter features (openaimodel3d.py:589-593): added to the stream behind input blocks 2, 5, 8, 11 -
+                # in place in the skip-concatenation buffer, so the skip carries them too, as `hs.append(h)` after the add does
+                fa = features_adapter[i // 3]
+                assert fa.shape == (c.F, ch, c.H, c.W), (tuple(fa.shape), (c.F, ch, c.H, c.W))
+                h.add_(fa.to(device=h.device, dtype=torch.float32).permute(0, 2, 3, 1).reshape(c.F * c.H * c.W, ch))
+                if hasattr(h, "_pm_gn_totals"):
+                    del h._pm_gn_totals  # (the producer's GroupNorm statistics describe the tensor before the add)
             bufs.append((buf, total - ch, c.H, c.W))
+        if features_adapter is not None:
+            assert len(features_adapter) == len(self.input_blocks) // 3, "Wrong features_adapter"
         buf, c_h, sh, sw = bufs.pop()
         h = self._run(c, self.middle_block, h, buf[:, :c_h])
         for k, module in enumerate(self.output_blocks):

@@ -113,7 +113,7 @@ def _run(seq, h, emb, context, batch):
     return h
 
 
-def forward(model, x, timesteps, context=None, fs=None):
+def forward(model, x, timesteps, context=None, fs=None, features_adapter=None):
     """`UNetModel.forward` with autograd (openaimodel3d.py:552-607): x (b, C_in, t, h, w), timesteps (b,),
     context (b, 77 + 16 t | L, D), fs (b,) -> (b, C_out, t, h, w)."""
     b, _, t, _, _ = x.shape
@@ -139,7 +139,11 @@ def forward(model, x, timesteps, context=None, fs=None):
         h = _run(module, h, emb, context, b)
         if i == 0 and model.addition_attention:
             h = _run(model.init_attn, h, emb, context, b)
+        if (i + 1) % 3 == 0 and features_adapter is not None:  # openaimodel3d.py:589-593
+            h = h + features_adapter[i // 3].to(h.dtype)
         hs.append(h)
+    if features_adapter is not None:
+        assert len(features_adapter) == len(model.input_blocks) // 3, "Wrong features_adapter"
     h = _run(model.middle_block, h, emb, context, b)
     for module in model.output_blocks:
         h = _run(module, torch.cat([h, hs.pop()], dim=1), emb, context, b)

@@ -41,6 +41,18 @@ def multicond_uc_img(ins, cond, uc):
             "c_concat": list(cond["c_concat"])}
 
 
+def adapter_features(mc, h, w, T=16, channel_mult=(1, 2, 4, 4)):
+    """`features_adapter` for UNetModel.forward (openaimodel3d.py:589-593): one (b t, C, H, W) tensor per input block id with
+    (id + 1) % 3 == 0 - the last ResBlock of every level at num_res_blocks = 2 - seeded, a few tenths of the stream's scale."""
+    feats = []
+    for lvl, mult in enumerate(channel_mult):
+        hh, ww = h, w
+        for _ in range(lvl):
+            hh, ww = (hh + 1) // 2, (ww + 1) // 2
+        feats.append(0.3 * module_input(f"adapter/{lvl}", T, mc * mult, hh, ww))
+    return feats
+
+
 def sampler_inputs(h, w, T=16):
     ins = synth.synth_inputs(h, w, T, seed=INPUT_SEED)
     cond = {"c_crossattn": [ins["c_crossattn"]], "c_concat": [ins["c_concat"]]}

@@ -133,6 +133,19 @@ def gen_unet_ctx():
     save("unet_small_ctx.npz", **out)
 
 
+def gen_unet_adapter():
+    """UNetModel.forward with `features_adapter` (openaimodel3d.py:584-596: added to the stream - and thereby to the skip -
+    behind input blocks 2, 5, 8, 11), the real module, reduced width."""
+    ref = rh.reference_unet(model_channels=64)
+    ref.load_state_dict(synth.synth_state_dict(ref, seed=WEIGHT_SEED))
+    ins, _, _ = _small_setup(64, 8, 8)
+    x = torch.cat([ins["x_T"], ins["c_concat"]], 1)
+    with torch.no_grad():
+        y = ref(x, torch.tensor([500]), context=ins["c_crossattn"], features_adapter=gr.adapter_features(64, 8, 8),
+                fs=torch.tensor([15]))
+    save("unet_small_adapter.npz", mc64_8x8_t500=y.numpy())
+
+
 def gen_ddim_small():
     import lvdm.models.samplers.ddim as refddim
     out = {}
@@ -429,6 +442,7 @@ if __name__ == "__main__":
     ap.add_argument("--ae", action="store_true")
     ap.add_argument("--rescale", action="store_true")
     ap.add_argument("--multicond", action="store_true")
+    ap.add_argument("--adapter", action="store_true")
     ap.add_argument("--resampler", action="store_true")
     ap.add_argument("--frames", action="store_true", help="reduced-width sampler -> decode_first_stage frames (seconds)")
     ap.add_argument("--frames-full", default="", help='full-width cases "S:eta,S:eta", e.g. "10:0,50:1" (hours of CPU)')
@@ -463,6 +477,10 @@ if __name__ == "__main__":
         assert rh.available()
         gen_ddim_multicond()
         sys.exit(0)
+    if a.adapter:
+        assert rh.available()
+        gen_unet_adapter()
+        sys.exit(0)
     if a.ae:
         assert rh.available()
         gen_ae()
@@ -478,6 +496,7 @@ if __name__ == "__main__":
         gen_modules()
         gen_unet_small()
         gen_unet_ctx()
+        gen_unet_adapter()
         gen_ddim_small()
         gen_ddim_rescale()
         gen_ddim_multicond()

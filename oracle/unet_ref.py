@@ -199,7 +199,7 @@ def _count_blocks(sd, stem):
 
 
 @torch.no_grad()
-def unet_forward(state_dict, x, timesteps, context, fs, model_channels=320):
+def unet_forward(state_dict, x, timesteps, context, fs, model_channels=320, features_adapter=None):
     """x (b, 8, t, h, w), timesteps (b,) long, context (b, 77 + 16 t, 1024), fs (b,) long
     -> (b, 4, t, h, w); everything in f32."""
     sd = _SD(state_dict)
@@ -224,7 +224,11 @@ def unet_forward(state_dict, x, timesteps, context, fs, model_channels=320):
         h = _run_sequential(sd, f"input_blocks.{i}.", h, emb, context, b)
         if i == 0 and sd.has("init_attn.0.norm.weight"):
             h = _run_sequential(sd, "init_attn.", h, emb, context, b)
+        if (i + 1) % 3 == 0 and features_adapter is not None:  # plug-in adapter features (openaimodel3d.py:589-593)
+            h = h + features_adapter[i // 3]
         hs.append(h)
+    if features_adapter is not None:
+        assert len(features_adapter) == n_in // 3, "Wrong features_adapter"
     h = _run_sequential(sd, "middle_block.", h, emb, context, b)
     for i in range(_count_blocks(sd, "output_blocks")):
         h = torch.cat([h, hs.pop()], dim=1)

@@ -98,6 +98,40 @@ def test_unet_small_against_reference(tag, mc, h, w, t, fs):
     assert rel(y, g[tag]) < 2e-5
 
 
+def test_unet_features_adapter_against_reference():
+    """`features_adapter` (openaimodel3d.py:584-596): the real module's output with four plug-in feature maps against (i) the
+    oracle's restatement and (ii) the PRODUCT U-Net on the oracle's op table (the in-place add into the skip-concatenation
+    buffer, inference path) and (iii) its differentiable training walk."""
+    from oracle.ops_torch import TorchOps
+    g = load("unet_small_adapter.npz")["mc64_8x8_t500"]
+    kw = dict(RH_KW, model_channels=64)
+    m = U.UNetModel(**kw).eval()
+    sd = _sd(m)
+    ins, _, _ = gr.sampler_inputs(8, 8)
+    x = torch.cat([ins["x_T"], ins["c_concat"]], 1)
+    fa = gr.adapter_features(64, 8, 8)
+    t, fs = torch.tensor([500]), torch.tensor([15])
+    y = unet_ref.unet_forward(sd, x, t, ins["c_crossattn"], fs, model_channels=64, features_adapter=fa)
+    assert rel(y, g) < 2e-5
+    assert rel(unet_ref.unet_forward(sd, x, t, ins["c_crossattn"], fs, model_channels=64), g) > 1e-2  # (the features matter)
+    m.load_state_dict(sd)
+    y2 = m.bind(TorchOps())(x, t, context=ins["c_crossattn"], features_adapter=fa, fs=fs)
+    assert rel(y2, g) < 2e-5
+    m.train()
+    for p_ in m.parameters():
+        p_.requires_grad_(True)
+    m.dropout = 0.0
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    y3 = m(x, t, context=ins["c_crossattn"], features_adapter=fa, fs=fs)
+    assert y3.requires_grad and rel(y3.detach(), g) < 5e-5
+    with pytest.raises(IndexError):  # (a short list: the reference indexes past its end too, openaimodel3d.py:591)
+        m.eval()(x, t, context=ins["c_crossattn"], features_adapter=fa[:3], fs=fs)
+    with pytest.raises(AssertionError, match="Wrong features_adapter"):  # (a long one: the reference's assert, :594-595)
+        m.eval()(x, t, context=ins["c_crossattn"], features_adapter=fa + fa[:1], fs=fs)
+
+
 @pytest.mark.parametrize("S,eta,cfg", gr.DDIM_SMALL_CASES)
 def test_ddim_small_against_reference(S, eta, cfg):
     g = load("ddim_small.npz")[f"S{S}_eta{eta:g}_cfg{cfg:g}"]

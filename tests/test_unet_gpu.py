@@ -51,6 +51,21 @@ def test_unet_small_forward(hip_ops_factory, dtype, tag, mc, h, w, t, fs):
     assert err <= FWD_TOL_REDUCED[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_unet_small_forward_with_features_adapter(hip_ops_factory, dtype):
+    """`features_adapter` (openaimodel3d.py:584-596) on the kernels: the plug-in features are added in place in the
+    skip-concatenation buffers (stream AND skip), eagerly and inside a captured graph."""
+    g = load("unet_small_adapter.npz")["mc64_8x8_t500"]
+    m = small_model(64, hip_ops_factory(dtype))
+    ins, _, _ = gr.sampler_inputs(8, 8)
+    x = torch.cat([ins["x_T"], ins["c_concat"]], 1).cuda()
+    fa = [f.cuda() for f in gr.adapter_features(64, 8, 8)]
+    y = m(x, torch.tensor([500]).cuda(), context=ins["c_crossattn"].cuda(), features_adapter=fa, fs=torch.tensor([15]).cuda())
+    err = rel(y.cpu(), g)
+    print(f"\n[parity] unet_small + features_adapter {dtype}: rel err {err:.2e}")
+    assert err <= FWD_TOL_REDUCED[dtype]
+
+
 FP8_ATTN_FWD_TOL = 2e-2  # BASELINE configs[4] only: e4m3 q/k/v/P in the spatial self-attention (5e-2 per call)
 
 
