@@ -421,6 +421,8 @@ class DDIMSampler:
                 unet.packed()  # re-packs (and moves the pack epoch in the key below) after an in-place weight edit
             tensors = ([v for d in (cc, uu or {}) + tuple(extra) for lst in d.values() for v in lst]
                        + ([fs] if torch.is_tensor(fs) else []))
+            for v in kwargs.values():  # tensors handed through to the U-Net (e.g. features_adapter): read in place by the graph
+                tensors += [v] if torch.is_tensor(v) else [w for w in v if torch.is_tensor(w)] if isinstance(v, (list, tuple)) else []
             # (a weight reload / .to() re-packs the kernel-side weights: the captured graph holds raw pointers to the
             # old ones, so the U-Net's pack epoch is part of the key)
             key = (tuple(x.shape), tuple((v.data_ptr(), tuple(v.shape), v._version) for v in tensors), tuple(sorted(kwargs)),

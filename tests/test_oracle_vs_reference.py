@@ -63,5 +63,5 @@ def test_multicond_sampler_is_dead_in_the_reference_and_its_working_form_is_ours
     mg.gen_ddim_multicond()
     new = np.load(tmp_path / "ddim_small_multicond.npz")
     old = np.load(os.path.join(os.path.dirname(__file__), "golden", "ddim_small_multicond.npz"))
-    for k in new.files:
-        assert np.array_equal(new[k], old[k]), k
+    for k in new.files:  # (to f32 rounding: the reference's reductions depend on the thread count the session happens to run with)
+        assert float(np.linalg.norm(new[k] - old[k]) / np.linalg.norm(old[k])) < 1e-5, k

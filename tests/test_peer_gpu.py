@@ -159,6 +159,7 @@ def test_mailbox_failure_on_one_rank_falls_back_on_every_rank(tmp_path):
 # host-staged exchange costs a scheduling quantum: the full-depth reduced-width model took 338 s in the mailbox-vs-P2P test):
 # two levels, one ResBlock per level - every kind of module and exchange is still there (init_attn, Down / Upsample, middle block)
 SHALLOW = dict(channel_mult=[1, 2], num_res_blocks=1, attention_resolutions=[1, 2])
+TINY = dict(channel_mult=[1], num_res_blocks=1, attention_resolutions=[1])  # one level: 20 + 5 latency-class, 10 bulk exchanges
 
 
 def _build(ops, fp, **over):
@@ -204,8 +205,10 @@ def _unet_worker(rank, world, port, out):
     try:
         from open_pandora_amd.frame_parallel import FrameParallel
         from open_pandora_amd.ops_hip import HipOps
+        import time
         ops = HipOps(torch.float16, "cuda:0")
         res = {}
+        t0 = time.time()
         # (i) full depth through the mailbox: exchange counts, and the result against the single-process run
         os.environ["PANDORA_PEER_MAILBOX"] = "1"
         fp = FrameParallel(16, ops=ops)
@@ -216,15 +219,18 @@ def _unet_worker(rank, world, port, out):
         res["mailbox_calls"] = dict(fp.calls)
         res["epoch"] = fp.mailbox.check()
         fp.mailbox.close()
-        # (ii) the mailbox against the torch.distributed point-to-point form of the same exchanges, shallow model (the gloo
+        res["seconds_full_depth_mailbox"] = time.time() - t0
+        # (ii) the mailbox against the torch.distributed point-to-point form of the same exchanges, one-level model (the gloo
         # P2P form costs a GPU scheduling quantum per exchange on a shared device)
         for tag, env in (("mailbox", "1"), ("p2p", "0")):
+            t0 = time.time()
             os.environ["PANDORA_PEER_MAILBOX"] = env
             fp = FrameParallel(16, ops=ops)
             assert (fp.mailbox is not None) == (env == "1")
-            res["shallow_" + tag] = _sample(_build(ops, fp, **SHALLOW))
+            res["shallow_" + tag] = _sample(_build(ops, fp, **TINY))
             if fp.mailbox is not None:
                 fp.mailbox.close()
+            res["seconds_tiny_" + tag] = time.time() - t0
         torch.save(res, f"{out}.{rank}")
     finally:
         dist.destroy_process_group()
@@ -322,5 +328,7 @@ def test_frame_sharded_unet_through_the_mailbox(tmp_path, hip_ops_factory, world
         assert c["mailbox"] == n_lat * per_fwd and got["epoch"] == c["mailbox"] - 1
         rccl_like = (c["all_to_all"] + c.get("gather_kv", 0)) // per_fwd
         assert rccl_like == n_bulk <= 35, c  # what is left for torch.distributed per forward (VERDICT r02 #3b)
-        print(f"\n[parity] frame shards world={world} rank {r}: mailbox == p2p bit for bit (shallow U-Net); full depth vs single "
-              f"process {err:.2e}; {c['mailbox'] // per_fwd} mailbox launches + {rccl_like} collectives per forward")
+        print(f"\n[parity] frame shards world={world} rank {r}: mailbox == p2p bit for bit (one-level U-Net); full depth vs single "
+              f"process {err:.2e}; {c['mailbox'] // per_fwd} mailbox launches + {rccl_like} collectives per forward "
+              f"(seconds: full-depth mailbox {got['seconds_full_depth_mailbox']:.0f}, one-level mailbox "
+              f"{got['seconds_tiny_mailbox']:.0f}, one-level p2p {got['seconds_tiny_p2p']:.0f})")
