@@ -39,7 +39,7 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16, MI355X_MICROARCH.md
 T = 16
 
 KERNELS = {
-    "gemm": "pm_gemm + pm_ln_gemm (dense nn.Linear / 1x1: gemm_kernel<A_DENSE> 2-stage, gemm_ring_kernel<A_DENSE>, gemm_ringw_kernel<A_DENSE> 256x128, gemm256_kernel, split-K reduce; ln_gemm_kernel = LayerNorm + projection at K = 320)",
+    "gemm": "pm_gemm + pm_ln_gemm (dense nn.Linear / 1x1: gemm_kernel<A_DENSE> 2-stage, gemm_ring_kernel<A_DENSE>, gemm_ringw_kernel<A_DENSE> 256x128, split-K reduce; ln_gemm_kernel = LayerNorm + projection at K = 320)",
     "conv3x3": "pm_conv2d_3x3 (gemm_ring_kernel<A_CONV3X3_FAST>; gemm_kernel for f32-operand / strided / upsampling convs)",
     "conv_t3": "pm_conv_temporal_k3 (gemm_kernel / gemm_ring_kernel<A_CONVT3>)",
     "attention": "pm_attention (attn_self_kernel: spatial self-attention; attn_kernel: text+image cross-attention)",

@@ -35,6 +35,19 @@
 // the workgroup) the counted wait would under-wait: from then on the waits are vmcnt(0).
 #include "gemm_common.hpp"
 
+// r04: since gemm_ringw_kernel exists this kernel only took the K < 512 whole-round launches (1 launch
+// of an 80-ms forward at 576x1024, 0.2-0.4 ms per step: -0.1 / -0.7 % in its own same-box A/B) - not worth 340 lines and a
+// dispatch rule in the shipped library.  It is RETIRED from it: compiled only into the diagnostics build (-DPM_DIAG,
+// PANDORA_GEMM256=1 / 2 there), kept as the measured record of the 256x256 8-phase design.
+#ifndef PM_DIAG
+namespace pm {
+bool gemm256_wanted(const GemmParams&, int, int) { return false; }
+template <typename T> int launch_gemm256(const GemmParams&, int, hipStream_t) { return PM_E_SHAPE; }
+template int launch_gemm256<f16>(const GemmParams&, int, hipStream_t);
+template int launch_gemm256<bf16>(const GemmParams&, int, hipStream_t);
+}  // namespace pm
+#else
+
 namespace pm {
 
 constexpr int BM2 = 256, BN2 = 256;
@@ -340,3 +353,4 @@ template int launch_gemm256<f16>(const GemmParams&, int, hipStream_t);
 template int launch_gemm256<bf16>(const GemmParams&, int, hipStream_t);
 
 }  // namespace pm
+#endif  // PM_DIAG
