@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256, (QB == 1 && RING == 2) ? 3 : 2) void attn_self
   char* const Ks = smem;
   char* const Vs = smem + RING * KV_TILE_BYTES;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ql = lane & 31, hh = lane >> 5;
   int wg = blockIdx.x;
   {  // XCD-aware: all query tiles of one (frame, head) run on one XCD (its K/V stays in that L2)
@@ -321,9 +321,28 @@ __global__ __launch_bounds__(256, (QB == 1 && RING == 2) ? 3 : 2) void attn_self
   const int nkt = (Nk + KV_TILE - 1) / KV_TILE;
   const int kc = (tid & 7) ^ ((lr >> 1) & 7);           // source-side swizzles: see attn_kernel
   const int vc = (tid & 7) ^ (((lr >> 1) & 1) << 2);
+  const int last_full = (Nk % KV_TILE == 0) ? nkt : nkt - 1;  // tiles [0, last_full) lie wholly inside the sequence
+  // Those tiles are fetched with `buffer_load ... lds`: per-lane offset fixed for the whole kernel, the tile's position in
+  // the SCALAR offset, the LDS stage in M0 - no vector instruction for addresses in the K loop (the global_load_lds form
+  // recomputes clamped 64-bit per-lane addresses, ~20 VALU incl. two v_mul_lo_u32 per tile, on a loop bound by vector
+  // issue).  (range = through the head slice of the last key row; no tile fetched this way reaches it)
+  const uint32_t kv_range = (uint32_t)(Nk - 1) * krs2 + 128u;
+  const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, (short)0, (int)kv_range, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, (short)0, (int)kv_range, 0x00020000);
+  const uint32_t kvoff = (uint32_t)lr * krs2 + (uint32_t)kc * 16, vvoff = (uint32_t)lr * krs2 + (uint32_t)vc * 16;
   auto load_kv = [&](int kt, int buf) {
+    if (kt < last_full) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < 2; ++j) {
+        const uint32_t soff = (uint32_t)(kt * KV_TILE + 32 * j) * krs2;
+        const int dst = buf * KV_TILE_BYTES + (32 * j + 8 * wave) * 128;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(krsrc, (lds_void*)(Ks + dst), 16, kvoff, soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (lds_void*)(Vs + dst), 16, vvoff, soff, 0, 0);
+      }
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {  // ragged last tile: rows clamped to the last key (masked by the careful tile)
       int key = kt * KV_TILE + lr + 32 * j;
       if (key > Nk - 1) key = Nk - 1;
       const int dst = buf * KV_TILE_BYTES + (32 * j + 8 * wave) * 128;
@@ -528,8 +547,7 @@ __global__ __launch_bounds__(256, (QB == 1 && RING == 2) ? 3 : 2) void attn_self
     if (t < nkt) load_kv(t, t);
   // three separate loops (careful first tile | fast tiles | careful ragged tile): with the two variants as the
   // arms of one loop body hipcc copied the 16-register accumulator tuples at every merge (~50 v_mov per tile)
-  const int last_full = (Nk % KV_TILE == 0) ? nkt : nkt - 1;  // tiles [1, last_full) need no masking
-  arrive(0);
+  arrive(0);  // (tiles [1, last_full) need no masking)
   tile(0, std::integral_constant<int, 0>{}, std::true_type{});
   int kt = 1;
   for (; kt + 3 < last_full; kt += 4) {  // four tiles per trip: every tile's stage is a compile-time constant
@@ -1138,6 +1156,7 @@ extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const voi
                     return check_launch())
 #ifdef PM_DIAG
   if (variant == 16) return launch_attn_self16(p, dtype, grid, (hipStream_t)stream);  // force the 16x16x32-MFMA form (attn16.hip)
+  if (variant == 17) return launch_attn_self16(p, dtype, grid, (hipStream_t)stream, false);  // ... with per-lane K/V addresses
   if (variant == 9)  // (kept for A/B runs: the round-1 kernel)
     PM_DISPATCH_DTYPE(dtype, T,
                       hipLaunchKernelGGL((attn_kernel<T, 1, false>), grid, dim3(256), 0, (hipStream_t)stream, p);

@@ -36,13 +36,19 @@ __device__ __forceinline__ float xor16(float v) { return __shfl_xor(v, 16, 64); 
 // (v_exp_f32) and an asm statement that reads it - gfx950's trans-forwarding hazard - and the sums come out wrong.)
 
 // (120 VGPRs, 32 KiB of LDS: four workgroups = 4 waves per SIMD are resident per CU)
-template <typename T>
+// DESC: K/V tiles that lie wholly inside the sequence are fetched with `buffer_load ... lds` - per-lane offset fixed for
+// the whole kernel, the tile's position in the SCALAR offset, the LDS stage in M0 - so that the K loop issues no vector
+// instruction for addresses (the global_load_lds form recomputes clamped 64-bit per-lane addresses: ~23 VALU incl. two
+// v_mul_lo_u32 of the ~127 a tile costs).  A ragged last tile keeps the clamped form.  Measured at N = 9216 (A/B in one
+// process, diagnostics variant 17 = per-lane addresses): -2.5 % cycles per workgroup at the same clock, +1.6 % by wall;
+// the same change in attn_self_kernel (attn.hip): -5.5 % cycles, of which the clock gives most back (1.79 -> 1.69 GHz).
+template <typename T, bool DESC>
 __global__ __launch_bounds__(256, 4) void attn_self16_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE_BYTES];  // K[2], V[2]
   char* const Ks = smem;
   char* const Vs = smem + 2 * KV_TILE_BYTES;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, g = lane >> 4;
   int wg = blockIdx.x;
   {  // XCD-aware: all query tiles of one (frame, head) run on one XCD (its K/V stays in that L2)
@@ -100,6 +106,20 @@ __global__ __launch_bounds__(256, 4) void attn_self16_kernel(const AttnParams p)
       const uint32_t row = (uint32_t)key * krs2;
       __builtin_amdgcn_global_load_lds((glb_void*)(kbase + (row + (uint32_t)kc * 16)), (lds_void*)(Ks + dst), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((glb_void*)(vbase + (row + (uint32_t)vc * 16)), (lds_void*)(Vs + dst), 16, 0, 0);
+    }
+  };
+  // (range = through the head slice of the last key row; a tile this form is used for never reaches it)
+  const uint32_t kv_range = (uint32_t)(Nk - 1) * krs2 + 128u;
+  const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, (short)0, (int)kv_range, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, (short)0, (int)kv_range, 0x00020000);
+  const uint32_t kvoff = (uint32_t)lr * krs2 + (uint32_t)kc * 16, vvoff = (uint32_t)lr * krs2 + (uint32_t)vc * 16;
+  auto load_kv_full = [&](int kt, int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t soff = (uint32_t)(kt * KV_TILE + 32 * j) * krs2;
+      const int dst = buf * KV_TILE_BYTES + (32 * j + 8 * wave) * 128;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(krsrc, (lds_void*)(Ks + dst), 16, kvoff, soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (lds_void*)(Vs + dst), 16, vvoff, soff, 0, 0);
     }
   };
 
@@ -231,12 +251,15 @@ __global__ __launch_bounds__(256, 4) void attn_self16_kernel(const AttnParams p)
   };
 
   // K/V double buffer: one barrier per tile (drains this wave's DMAs, publishes tile t, frees tile t-1's stage)
+  const int last_full = (Nk % KV_TILE == 0) ? nkt : nkt - 1;  // tiles [1, last_full) need no masking
   auto arrive = [&](int t) {
     __syncthreads();
-    if (t + 1 < nkt) load_kv(t + 1, (t + 1) & 1);
+    if (t + 1 < nkt) {
+      if (DESC && t + 1 < last_full) load_kv_full(t + 1, (t + 1) & 1);
+      else load_kv(t + 1, (t + 1) & 1);
+    }
   };
   load_kv(0, 0);
-  const int last_full = (Nk % KV_TILE == 0) ? nkt : nkt - 1;  // tiles [1, last_full) need no masking
   arrive(0);
   tile(0, std::integral_constant<int, 0>{}, std::true_type{});
   int kt = 1;
@@ -281,8 +304,14 @@ __global__ __launch_bounds__(256, 4) void attn_self16_kernel(const AttnParams p)
 
 // launcher used by pm_attention (attn.hip)
 namespace pm {
-int launch_attn_self16(const AttnParams& p, int dtype, dim3 grid, hipStream_t stream) {
-  PM_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_self16_kernel<T>), grid, dim3(256), 0, stream, p);
+int launch_attn_self16(const AttnParams& p, int dtype, dim3 grid, hipStream_t stream, bool desc) {
+  if constexpr (PM_DIAG_BUILD) {
+    if (!desc) {  // (A/B runs: the per-lane-address form of the K/V fetch)
+      PM_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_self16_kernel<T, false>), grid, dim3(256), 0, stream, p);
+                        return check_launch());
+    }
+  }
+  PM_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_self16_kernel<T, true>), grid, dim3(256), 0, stream, p);
                     return check_launch());
 }
 }  // namespace pm
