@@ -215,6 +215,7 @@ def _segments_supported(fp, dev):
     is the same on every path: a rank whose capture raised still issues the rehearsal all-reduce (on a
     plain buffer) before the flag exchange, so RCCL never pairs collectives of different size / dtype."""
     import torch.distributed as dist
+    from .frame_parallel import control_collective
     ok = 1
     side = _capture_streams(dev)[0]
     buf = pool = None
@@ -252,7 +253,7 @@ def _segments_supported(fp, dev):
     except Exception:  # noqa: BLE001
         ok = 0
     flag = torch.tensor([ok], device=dev if fp.backend == "nccl" else "cpu", dtype=torch.int32)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=fp.group)
+    control_collective(lambda: dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=fp.group), fp.group)
     return bool(flag.item())
 
 
@@ -310,7 +311,8 @@ class DDIMSampler:
             import torch.distributed as dist
             seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
             t = seed.to(device) if dist.get_backend() == "nccl" else seed
-            dist.broadcast(t, src=0)
+            from .frame_parallel import control_collective
+            control_collective(lambda: dist.broadcast(t, src=0))
             # a generator ON the device: identical GPUs give identical Philox streams, and no host randn + blocking
             # H2D copy sits in the step loop
             self._gen = torch.Generator(device=device).manual_seed(int(t.item()))

@@ -80,7 +80,7 @@ class PeerMailbox:
             self.lib.pm_peer_destroy(base)
             rc = -1
         infos = [None] * self.world
-        dist.all_gather_object(infos, (int(rc), bytes(handle.raw)), group=self.group)
+        control_collective(lambda: dist.all_gather_object(infos, (int(rc), bytes(handle.raw)), group=self.group), self.group)
         if any(i[0] != 0 for i in infos):
             if rc == 0:
                 self.lib.pm_peer_destroy(base)
@@ -97,7 +97,8 @@ class PeerMailbox:
                     continue
                 self.peers[r] = p
         flags = [None] * self.world
-        dist.all_gather_object(flags, bad, group=self.group)  # (also: every mailbox is mapped everywhere before the first write)
+        # (also: every mailbox is mapped everywhere before the first write)
+        control_collective(lambda: dist.all_gather_object(flags, bad, group=self.group), self.group)
         if any(flags):
             self._release()
             raise PeerUnavailable(f"pm_peer_open failed on rank(s) {[r for r, f in enumerate(flags) if f]}")
@@ -126,7 +127,7 @@ class PeerMailbox:
         finally:
             self.timeout_s = keep
         res = [None] * self.world
-        dist.all_gather_object(res, (ok, why), group=self.group)
+        control_collective(lambda: dist.all_gather_object(res, (ok, why), group=self.group), self.group)
         if all(r[0] for r in res):
             return True, ""
         self.close()
@@ -144,7 +145,7 @@ class PeerMailbox:
         if self.base is None:
             return
         torch.cuda.synchronize(self.ops.device)
-        dist.barrier(group=self.group)  # nobody still writes into a mailbox that is about to go
+        control_collective(lambda: dist.barrier(group=self.group), self.group)  # nobody still writes into a mailbox that is about to go
         self._release()
 
     def check(self, collective=False):
@@ -161,7 +162,7 @@ class PeerMailbox:
         bad = [self.rank] if err.value else []
         if collective:
             flags = [None] * self.world
-            dist.all_gather_object(flags, int(err.value != 0), group=self.group)
+            control_collective(lambda: dist.all_gather_object(flags, int(err.value != 0), group=self.group), self.group)
             bad = [r for r, f in enumerate(flags) if f]
             if bad:
                 self.close()
@@ -208,6 +209,16 @@ def _on_comm_stream(fn):
     with torch.cuda.stream(cs):
         fn()
     cur.wait_stream(cs)
+
+
+def control_collective(fn, group=None):
+    """A control-plane collective (object gathers, barriers, flags, the seed broadcast): under RCCL it goes through the
+    dedicated communication stream like the data-path ones - the watchdog polls its end event too, and the stream the
+    caller is on may start capturing right afterwards (FrameParallel._comm has the story)."""
+    if torch.cuda.is_available() and torch.cuda.is_initialized() and dist.get_backend(group) == "nccl":
+        _on_comm_stream(fn)
+    else:
+        fn()
 
 
 def _host_staged_sync(t, group=None):
