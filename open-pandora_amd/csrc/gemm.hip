@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     const int kt0 = split * p.ktps;
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
-      int n = n0 + cperm(lr + RSTEP * j, p.act == PM_ACT_GEGLU);  // LDS row -> output column (epilogue_regs)
+      int n = n0 + cperm(lr + RSTEP * j, p.act == PM_ACT_GEGLU || p.natural);  // LDS row -> output column (epilogue_regs)
       if (n > p.N - 1) n = p.N - 1;
       b_off[j] = (uint32_t)(((int64_t)n * p.ldw + lc * 8) * 2);
     }
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int pr = 32 * j + 8 * lw + r8;  // LDS row of the W tile -> output column (see epilogue_regs)
-        int n = n0 + cperm(pr, p.act == PM_ACT_GEGLU);
+        int n = n0 + cperm(pr, p.act == PM_ACT_GEGLU || p.natural);
         if (n > p.N - 1) n = p.N - 1;
         b_off[j] = (uint32_t)(((int64_t)n * p.ldw + lc * 8) * 2);
         int m = m0 + 32 * j + 8 * lw + r8;
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ringw_kernel(const GemmParams p) 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int pr = 32 * j + 8 * lw + r8;  // LDS row of the W tile -> output column (see epilogue_regs)
-        int n = n0 + cperm(pr, p.act == PM_ACT_GEGLU);
+        int n = n0 + cperm(pr, p.act == PM_ACT_GEGLU || p.natural);
         if (n > p.N - 1) n = p.N - 1;
         b_off[j] = (uint32_t)(((int64_t)n * p.ldw + lc * 8) * 2);
       }
@@ -1284,6 +1284,7 @@ static int g_ring = 1;  // PANDORA_GEMM_RING: 0 = never, 1 = by prefer_ring(), 2
 static int g_ringw = 1;  // PANDORA_GEMM_RINGW: 0 = never, 1 = by prefer_ringw(), 2 (with PANDORA_GEMM_RING=2) = every unsplit 16-bit call
 static int g_ring_max_work = 0;  // PANDORA_GEMM_RING_MAX_WORK > 0: never use the ring kernel above that many work items
 static int g_num_cus[MAX_DEVICES] = {0};
+static int g_natural = 1;          // PANDORA_GEMM_NATURAL (diagnostics build): 0 = interleaved W rows for the f32 flavours too (A/B)
 static int g_persist_per_cu = 0;    // PANDORA_GEMM_PERSIST: persistent 2-stage workgroups per CU (0 = one work item per workgroup; measured: 2/CU = no gain, 1 or 3/CU 5 % slower)
 static int g_split_min_nk = 24;     // PANDORA_SPLITK_MIN_NK: shortest K loop (in 64-wide tiles) that is split
 static int g_split_model = 1;       // PANDORA_SPLITK_MODEL: 0 = the round-1 rule (aim at 512 work items), for A/B runs
@@ -1314,6 +1315,8 @@ static void init_once() {
     if (sf) g_split_force = atoi(sf);
     const char* ps = diag_env("PANDORA_GEMM_PERSIST");
     if (ps) g_persist_per_cu = atoi(ps);
+    const char* nl = diag_env("PANDORA_GEMM_NATURAL");
+    if (nl) g_natural = atoi(nl);
     return true;
   }();
   (void)init;
@@ -1390,6 +1393,12 @@ static void plan_split(GemmParams& p, void* workspace, size_t workspace_bytes, b
   p.splits = s;
   p.ktps = ktps;
   p.ws = reinterpret_cast<float*>(workspace);
+  // all-f32 epilogue (f32 output - its residual, if any, is f32 too - or split-K slabs) on the fast flavour's
+  // preconditions: W rows staged in natural column order, 64 contiguous bytes per row and store / residual-load
+  // instruction (gemm_common.hpp cperm)
+  const int64_t ldc = s > 1 ? p.N : p.ldc;
+  p.natural = (g_natural && p.act != PM_ACT_GEGLU && (p.out32 || s > 1) && (p.N & 31) == 0 && (ldc & 7) == 0 &&
+               (p.R == nullptr || (p.ldr & 7) == 0)) ? 1 : 0;
 }
 
 template <typename T> static void launch_reduce(const GemmParams& p, hipStream_t stream) {

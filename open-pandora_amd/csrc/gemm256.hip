@@ -82,6 +82,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const GemmParams p) {
   const int nk = p.K / BK;
   const int ntiles_total = p.mtiles * p.ntiles;
   const bool geglu = p.act == PM_ACT_GEGLU;
+  const bool wnat = geglu || p.natural;  // (W rows in natural column order: gemm_common.hpp cperm)
 
   // ---- work walk (the ring kernel's): workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its
   // own L2.  XCD x owns the CONTIGUOUS run [x*per, (x+1)*per) of the supertile-ordered work list and its G/8 workgroups
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const GemmParams p) {
   };
   bool tail = false;  // a staging slot has found nothing to fetch: counted waits would under-wait from here on
   // per-lane constants of the staged rows: A rows srow + 128 j (+ 64 Y for half Y); W columns cperm(...) (+ 32 X)
-  const int cb0 = cperm((srow >> 5) * 64 + (srow & 31), geglu), cb1 = cperm((2 + (srow >> 5)) * 64 + (srow & 31), geglu);
+  const int cb0 = cperm((srow >> 5) * 64 + (srow & 31), wnat), cb1 = cperm((2 + (srow >> 5)) * 64 + (srow & 31), wnat);
   const int64_t lda2 = p.lda * 2, ldw2 = p.ldw * 2;
   const uint32_t lc16 = (uint32_t)lc * 16;
   auto stream_origin = [&](Stream& s, bool is_a) {

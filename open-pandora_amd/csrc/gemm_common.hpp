@@ -30,6 +30,7 @@ struct GemmParams {
   int splits, ktps;  // split-K: number of K slices and K-tiles per slice
   float* ws;         // split-K partial slabs [splits][M][N] f32
   float* colstats;   // optional [ceil(M/64)][Nout][2]: column {sum, sum of squares} of every 64 output rows
+  int natural;       // W rows staged in natural column order (see cperm): GEGLU, and the all-f32 epilogue flavours
   // conv3x3
   int Hin, Win, Hv, Wv, Cin, Ho, Wo, stride, ups, pad;  // pad: zero rows/cols before the image (1, or 0)
   // temporal conv: F frames of P pixels; clips of Fc frames (Fc divides F) are independent: zero padding at BOTH ends of each
@@ -68,14 +69,22 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // as much as 12 K-steps of the main loop).
 //   LDS row pr of the W tile holds output column n0 + cperm(pr); GEGLU keeps the natural order (its
 //   [16 value | 16 gate] weight packing IS the block pair).
-__device__ __forceinline__ int cperm(int pr, bool geglu) {
+//   All-f32 flavours (f32 output or split-K slabs, residual none or f32: GemmParams::natural, set by the host) keep the
+//   natural order too: a lane's block j is then the 16-byte f32 run at column 16 j + 4 fq, and the four lanes fq = 0..3
+//   of a row write (and read the residual as) 64 CONTIGUOUS bytes per instruction; with the interleave a lane owns 32
+//   contiguous bytes that two instructions cover half each - every 64-byte request half used.
+__device__ __forceinline__ int cperm(int pr, bool natural) {
   const int nn = pr & 15, jb = (pr >> 4) & 3;
-  return geglu ? pr : (pr & ~63) + (jb >> 1) * 32 + (nn >> 2) * 8 + (jb & 1) * 4 + (nn & 3);
+  return natural ? pr : (pr & ~63) + (jb >> 1) * 32 + (nn >> 2) * 8 + (jb & 1) * 4 + (nn & 3);
+}
+// column offset (inside a wave's 64) of the 4-column run h (0 / 1) of block pair jp held by lane group fq
+__device__ __forceinline__ int run_col(int jp, int h, int fq, bool natural) {
+  return natural ? jp * 32 + h * 16 + fq * 4 : jp * 32 + fq * 8 + h * 4;
 }
 // bias of this lane's 16 output columns, bv[j][r] <-> column block j, column 4*fq + r in MFMA order
 __device__ __forceinline__ void load_bias_regs(const GemmParams& p, float (&bv)[4][4], int n0, int wn, int fq) {
   const float* bias_p = (p.splits > 1) ? nullptr : p.bias;
-  const bool geglu = p.act == PM_ACT_GEGLU;
+  const bool geglu = p.act == PM_ACT_GEGLU || p.natural;
   // column of element (j, 0): the 4 elements r = 0..3 are consecutive columns -> one 16-byte load per j when the
   // run lies inside [0, N) (N % 4 == 0 on every shape of the path); clamped address + select otherwise
 #pragma unroll
@@ -102,13 +111,17 @@ template <typename T, bool OUT32, int RES>
 __device__ __forceinline__ void store_fast(const GemmParams& p, f32x4 (&acc)[4][4], void* cbase, int64_t ldc,
                                            int mrow0, int ncol0, int nout, int fr, int fq, bool stats,
                                            float (&cs)[2][8], float (&cq)[2][8]) {
+  // f32 flavours in natural column order (GemmParams::natural, wave-uniform; N % 32 == 0 there, so the two runs of a pair
+  // share one fate as the interleaved ones do): run 1 of pair jp sits 16 columns, not 4, behind run 0 (run_col)
+  const bool nat = OUT32 && RES != 1 && p.natural != 0;
+  const int hstep = nat ? 16 : 4;
   int ncl[2];
   bool nok[2];
 #pragma unroll
   for (int jp = 0; jp < 2; ++jp) {
-    const int n = ncol0 + jp * 32 + fq * 8;
+    const int n = ncol0 + run_col(jp, 0, fq, nat);
     nok[jp] = n < nout;
-    ncl[jp] = nok[jp] ? n : 0;
+    ncl[jp] = nok[jp] ? n : 0;  // dead lanes: clamped addresses, predicated stores
   }
 #pragma unroll
   for (int ih = 0; ih < 2; ++ih) {  // two row-block halves: bounds the residual registers in flight
@@ -128,7 +141,7 @@ __device__ __forceinline__ void store_fast(const GemmParams& p, f32x4 (&acc)[4][
         } else if constexpr (RES == 2) {
           const float* rp = reinterpret_cast<const float*>(p.R) + rowoff[ii] * p.ldr + ncl[jp];
           r32[ii][jp][0] = *reinterpret_cast<const f32x4*>(rp);
-          r32[ii][jp][1] = *reinterpret_cast<const f32x4*>(rp + 4);
+          r32[ii][jp][1] = *reinterpret_cast<const f32x4*>(rp + hstep);
         }
       }
     }
@@ -168,7 +181,7 @@ __device__ __forceinline__ void store_fast(const GemmParams& p, f32x4 (&acc)[4][
           if constexpr (OUT32) {
             float* cptr = reinterpret_cast<float*>(cbase) + rowoff[ii] * ldc + ncl[jp];
             *reinterpret_cast<f32x4*>(cptr) = f32x4{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(cptr + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            *reinterpret_cast<f32x4*>(cptr + hstep) = f32x4{v[4], v[5], v[6], v[7]};
           } else {
             Pack8<T> ov;
 #pragma unroll
@@ -196,7 +209,15 @@ __device__ __forceinline__ bool residual_into_acc(const GemmParams& p, f32x4 (&a
     if (m > p.M - 1) m = p.M - 1;
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
-      int n = n0 + wn * 64 + jp * 32 + fq * 8;
+      int n = n0 + wn * 64 + run_col(jp, 0, fq, p.natural != 0);
+      if (p.natural) {  // (implies an f32 residual and N % 32 == 0: two 16-byte runs 16 columns apart, store_fast)
+        int nb = n0 + wn * 64 + jp * 32;  // (dead column groups: clamped to the last one)
+        if (nb > p.N - 32) nb = p.N - 32;
+        const float* rp = reinterpret_cast<const float*>(p.R) + (int64_t)m * p.ldr + nb + fq * 4;
+        acc[i][2 * jp] = *reinterpret_cast<const f32x4*>(rp);
+        acc[i][2 * jp + 1] = *reinterpret_cast<const f32x4*>(rp + 16);
+        continue;
+      }
       if (n > p.N - 8) n = p.N - 8;
       if (f32res) {
         const float* rp = reinterpret_cast<const float*>(p.R) + (int64_t)m * p.ldr + n;
@@ -307,16 +328,19 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, f32x4 (&acc)[
           }
         }
       if (fr == 0 && sblock * 64 < p.M) {  // (a ragged last tile has no second block)
+        const bool nat = out32 && Rg == nullptr && p.natural != 0;  // (as store_fast)
 #pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-          const int n = ncol0 + jp * 32 + fq * 8;
-          if (n < nout) {
-            float* dst = p.colstats + ((int64_t)sblock * nout + n) * 2;
+        for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
-            for (int e = 0; e < 8; e += 2)
-              *reinterpret_cast<f32x4*>(dst + 2 * e) = f32x4{cs[jp][e], cq[jp][e], cs[jp][e + 1], cq[jp][e + 1]};
+          for (int h = 0; h < 2; ++h) {
+            const int n = ncol0 + run_col(jp, h, fq, nat);
+            if (n < nout) {
+              float* dst = p.colstats + ((int64_t)sblock * nout + n) * 2;
+#pragma unroll
+              for (int e = 4 * h; e < 4 * h + 4; e += 2)
+                *reinterpret_cast<f32x4*>(dst + 2 * (e - 4 * h)) = f32x4{cs[jp][e], cq[jp][e], cs[jp][e + 1], cq[jp][e + 1]};
+            }
           }
-        }
       }
     }
     return;
