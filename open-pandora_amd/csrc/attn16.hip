@@ -42,7 +42,16 @@ __device__ __forceinline__ float xor16(float v) { return __shfl_xor(v, 16, 64); 
 // v_mul_lo_u32 of the ~127 a tile costs).  A ragged last tile keeps the clamped form.  Measured at N = 9216 (A/B in one
 // process, diagnostics variant 17 = per-lane addresses): -2.5 % cycles per workgroup at the same clock, +1.6 % by wall;
 // the same change in attn_self_kernel (attn.hip): -5.5 % cycles, of which the clock gives most back (1.79 -> 1.69 GHz).
-template <typename T, bool DESC>
+// MSUM: the softmax denominators come out of the matrix pipe - one more MFMA per (32-key half, query block) whose A operand
+// is a constant all-ones fragment: every row of its 16 x 16 result block is sum_k P^T[k][q], accumulated in f32 over the
+// SAME 16-bit P the numerator uses (a row's weights then sum to one exactly), already replicated over the lanes that need
+// it.  4 MFMAs per tile replace 32 v_add_f32 and the two cross-lane sums at the end.  Measured (N = 9216, A/B in one process,
+// diagnostics variant 18 = sums on the vector pipe): -0.6 % cycles, +2.0 % by wall (1088 -> 1111 TF/s); error against an
+// f64 softmax attention unchanged (2.92e-3 bf16 / 3.63e-4 f16 either way, tools/diag/attn_msum_accuracy.py).  That a
+// quarter of the loop's vector instructions buys 0.6 % of its cycles - and four more MFMAs cost nothing - says the loop
+// is bound by neither pipe's issue rate but by the dependent chain of a tile (LDS read -> MFMA -> max -> exp -> MFMA)
+// at four waves per SIMD.
+template <typename T, bool DESC, bool MSUM>
 __global__ __launch_bounds__(256, 4) void attn_self16_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE_BYTES];  // K[2], V[2]
   char* const Ks = smem;
@@ -125,10 +134,16 @@ __global__ __launch_bounds__(256, 4) void attn_self16_kernel(const AttnParams p)
 
   f32x4 oacc[4][2], nm[2];  // nm: every register = -m_run, the initial accumulator of the S^T chains
   float m_run[2], l_run[2];
+  f32x4 lacc[2];  // MSUM: every register = the running denominator of the lane's query row in block qb
+  Pack8<T> ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones.e[e] = from_f32<T>(1.0f);
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     m_run[qb] = 0.f;
     l_run[qb] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lacc[qb][r] = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) nm[qb][r] = 0.f;
     asm volatile("" : "+v"(nm[qb]));
@@ -154,6 +169,8 @@ __global__ __launch_bounds__(256, 4) void attn_self16_kernel(const AttnParams p)
       rmx = fmaxf(rmx, 0.f);  // never lower m: rows that did not outgrow it keep alpha == 1 exactly
       const float alpha = __builtin_amdgcn_exp2f(-rmx);
       l_run[qb] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lacc[qb][r] *= alpha;
 #pragma unroll
       for (int db = 0; db < 4; ++db)
 #pragma unroll
@@ -232,10 +249,16 @@ __global__ __launch_bounds__(256, 4) void attn_self16_kernel(const AttnParams p)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float pe = __builtin_amdgcn_exp2f(sacc[kb][qb][r]);
-          ps[r] = kb ? ps[r] + pe : pe;
+          if constexpr (!MSUM) ps[r] = kb ? ps[r] + pe : pe;
           pf[kb >> 1][qb].e[4 * (kb & 1) + r] = from_f32<T>(pe);
         }
-      l_run[qb] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+      if constexpr (!MSUM) l_run[qb] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    }
+    if constexpr (MSUM) {
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) lacc[qb] = mfma16(ones.v, pf[kh][qb].v, lacc[qb]);
     }
     // ---- O^T += V^T . P^T ----
 #pragma unroll
@@ -276,8 +299,13 @@ __global__ __launch_bounds__(256, 4) void attn_self16_kernel(const AttnParams p)
 
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
-    float l_tot = l_run[qb] + xor16(l_run[qb]);
-    l_tot += other_half(l_tot);
+    float l_tot;
+    if constexpr (MSUM) {
+      l_tot = lacc[qb][0];
+    } else {
+      l_tot = l_run[qb] + xor16(l_run[qb]);
+      l_tot += other_half(l_tot);
+    }
     const float inv = 1.0f / l_tot;
     if (q_valid[qb]) {
       T* op = reinterpret_cast<T*>(p.o) + (int64_t)b * p.o_bs + (int64_t)qrow[qb] * p.o_rs + head * 64 + 4 * g;
@@ -304,14 +332,18 @@ __global__ __launch_bounds__(256, 4) void attn_self16_kernel(const AttnParams p)
 
 // launcher used by pm_attention (attn.hip)
 namespace pm {
-int launch_attn_self16(const AttnParams& p, int dtype, dim3 grid, hipStream_t stream, bool desc) {
-  if constexpr (PM_DIAG_BUILD) {
-    if (!desc) {  // (A/B runs: the per-lane-address form of the K/V fetch)
-      PM_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_self16_kernel<T, false>), grid, dim3(256), 0, stream, p);
+int launch_attn_self16(const AttnParams& p, int dtype, dim3 grid, hipStream_t stream, int form) {
+  if constexpr (PM_DIAG_BUILD) {  // (A/B runs: 1 = per-lane addresses of the K/V fetch, 2 = row sums on the vector pipe)
+    if (form == 1) {
+      PM_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_self16_kernel<T, false, true>), grid, dim3(256), 0, stream, p);
+                        return check_launch());
+    }
+    if (form == 2) {
+      PM_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_self16_kernel<T, true, false>), grid, dim3(256), 0, stream, p);
                         return check_launch());
     }
   }
-  PM_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_self16_kernel<T, true>), grid, dim3(256), 0, stream, p);
+  PM_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_self16_kernel<T, true, true>), grid, dim3(256), 0, stream, p);
                     return check_launch());
 }
 }  // namespace pm

@@ -25,7 +25,7 @@ struct AttnParams {
   unsigned long long* stamps;
 };
 
-int launch_attn_self16(const AttnParams& p, int dtype, dim3 grid, hipStream_t stream, bool desc = true);  // attn16.hip
+int launch_attn_self16(const AttnParams& p, int dtype, dim3 grid, hipStream_t stream, int form = 0);  // attn16.hip
 
 constexpr int KV_TILE = 64;
 constexpr int KV_TILE_BYTES = KV_TILE * 128;  // 64 keys x 64 dims x 2 B
