@@ -1158,6 +1158,7 @@ extern "C" int pm_attention(const void* q, int64_t q_bs, int64_t q_rs, const voi
   if (variant == 16) return launch_attn_self16(p, dtype, grid, (hipStream_t)stream);  // force the 16x16x32-MFMA form (attn16.hip)
   if (variant == 17) return launch_attn_self16(p, dtype, grid, (hipStream_t)stream, 1);  // ... with per-lane K/V addresses
   if (variant == 18) return launch_attn_self16(p, dtype, grid, (hipStream_t)stream, 2);  // ... with the row sums on the vector pipe
+  if (variant == 19) return launch_attn_self16(p, dtype, grid, (hipStream_t)stream, 3);  // ... with hipcc's own PV issue order
   if (variant == 9)  // (kept for A/B runs: the round-1 kernel)
     PM_DISPATCH_DTYPE(dtype, T,
                       hipLaunchKernelGGL((attn_kernel<T, 1, false>), grid, dim3(256), 0, (hipStream_t)stream, p);

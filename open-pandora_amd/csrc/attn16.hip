@@ -51,7 +51,12 @@ __device__ __forceinline__ float xor16(float v) { return __shfl_xor(v, 16, 64); 
 // quarter of the loop's vector instructions buys 0.6 % of its cycles - and four more MFMAs cost nothing - says the loop
 // is bound by neither pipe's issue rate but by the dependent chain of a tile (LDS read -> MFMA -> max -> exp -> MFMA)
 // at four waves per SIMD.
-template <typename T, bool DESC, bool MSUM>
+// PVPIPE: the PV phase's issue order pinned with sched_group_barrier (see the end of tile()): -0.9 % cycles, +0.7...1.1 %
+// by wall at N = 9216 / 4608 against hipcc's own order (diagnostics variant 19).  With the denominators on the matrix
+// pipe the loop's issue costs sum to ~745 cycles per wave and tile (32 v_exp x 8 + 16 v_cvt_pk x 4.5 + 21 max x 4 +
+// 11 address / compare x 4 + 36 MFMA issue holds x 8, MI355X_MICROARCH.md); the kernel runs 836: what is left to a perfect
+// schedule at this instruction mix is ~11 %, i.e. ~0.49 of the dense peak at the clock the chip holds.
+template <typename T, bool DESC, bool MSUM, bool PVPIPE>
 __global__ __launch_bounds__(256, 4) void attn_self16_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE_BYTES];  // K[2], V[2]
   char* const Ks = smem;
@@ -254,6 +259,7 @@ __global__ __launch_bounds__(256, 4) void attn_self16_kernel(const AttnParams p)
         }
       if constexpr (!MSUM) l_run[qb] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
     }
+    if constexpr (PVPIPE) __builtin_amdgcn_sched_barrier(0);
     if constexpr (MSUM) {
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
@@ -270,6 +276,20 @@ __global__ __launch_bounds__(256, 4) void attn_self16_kernel(const AttnParams p)
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) oacc[db][qb] = mfma16(vf, pf[kh][qb].v, oacc[db][qb]);
       }
+    }
+    if constexpr (PVPIPE) {
+      // issue order pinned: the first two V fragments' reads, the LDS-free denominator MFMAs under their latency, then
+      // fragment f + 2's reads right behind fragment f's MFMAs (two register sets; left alone hipcc issues a row block's
+      // four reads only after the previous block's four MFMAs and exposes every read's full latency)
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      if constexpr (MSUM) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+      for (int f = 0; f < 6; ++f) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -335,15 +355,21 @@ namespace pm {
 int launch_attn_self16(const AttnParams& p, int dtype, dim3 grid, hipStream_t stream, int form) {
   if constexpr (PM_DIAG_BUILD) {  // (A/B runs: 1 = per-lane addresses of the K/V fetch, 2 = row sums on the vector pipe)
     if (form == 1) {
-      PM_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_self16_kernel<T, false, true>), grid, dim3(256), 0, stream, p);
+      PM_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_self16_kernel<T, false, true, false>), grid, dim3(256), 0, stream, p);
                         return check_launch());
     }
     if (form == 2) {
-      PM_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_self16_kernel<T, true, false>), grid, dim3(256), 0, stream, p);
+      PM_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_self16_kernel<T, true, false, false>), grid, dim3(256), 0, stream, p);
                         return check_launch());
     }
   }
-  PM_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_self16_kernel<T, true, true>), grid, dim3(256), 0, stream, p);
+  if constexpr (PM_DIAG_BUILD) {
+    if (form == 3) {  // hipcc's own issue order in the PV phase
+      PM_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_self16_kernel<T, true, true, false>), grid, dim3(256), 0, stream, p);
+                        return check_launch());
+    }
+  }
+  PM_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_self16_kernel<T, true, true, true>), grid, dim3(256), 0, stream, p);
                     return check_launch());
 }
 }  // namespace pm

@@ -83,7 +83,7 @@ def main():
             t = sorted(res[vv])
             med, mn = t[len(t) // 2], t[0]
             c = sorted(clk[vv])[1]
-            print(f"N={N:5d} heads={heads:2d} variant {vv:2d} ({'32x32x16, 3 waves/SIMD' if vv == 1 else '16x16x32, 4 waves/SIMD' if vv == 16 else 'auto' if vv == 0 else '16x16x32 with per-lane K/V addresses' if vv == 17 else '16x16x32 with the row sums on the vector pipe' if vv == 18 else 'other'}): "
+            print(f"N={N:5d} heads={heads:2d} variant {vv:2d} ({'32x32x16, 3 waves/SIMD' if vv == 1 else '16x16x32, 4 waves/SIMD' if vv == 16 else 'auto' if vv == 0 else '16x16x32 with per-lane K/V addresses' if vv == 17 else '16x16x32 with the row sums on the vector pipe' if vv == 18 else '16x16x32 with the compiler-chosen PV issue order' if vv == 19 else 'other'}): "
                   f"median {med:.3f} ms ({fl / med / 1e9:7.1f} TF/s = {fl / med / 1e9 / 2500:.3f} of 2.5 PF)  "
                   f"min {mn:.3f} ms ({fl / mn / 1e9:7.1f} TF/s)  in-kernel clock {c[0]:.3f} GHz, "
                   f"{c[1] / 1e3:.1f} k cycles per workgroup")
