@@ -669,7 +669,7 @@ def main():
             out["roofline_attention"] = {
                 "bound": "mfma", "kernel": ("pm_attention_fp8 (attn_fp8_pack_kernel + attn_fp8_kernel, e4m3 on the block-scaled MFMA; "
                                             "priced against the DENSE BF16 peak like the bf16 kernel: the fp8 dense peak is 2x)"
-                                            if a.fp8_attention else "pm_attention (attn_self_kernel)") +
+                                            if a.fp8_attention else "pm_attention (attn_self16_kernel: v_mfma_f32_16x16x32, denominators on the matrix pipe)") +
                                            ": spatial self-attention, N = 9216 tokens x 16 frames x 5 heads x head dim 64 "
                                            "(576x1024, U-Net level 0)",
                 "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
