@@ -110,4 +110,6 @@ def test_segmented_graph_replay_of_frame_sharded_forward(tmp_path, kv_gather):
     err = ((got["seg"] - got["plain"]).norm() / got["plain"].norm()).item()
     print(f"\n[parity] segmented replay over RCCL (1 rank, {'K|V all-gather' if kv_gather else 'frames<->pixels re-shard'}): "
           f"== eager sharded run bit for bit; vs unsharded {err:.2e}; {got['n_comm']} RCCL calls between {got['n_comm'] + 1} graphs")
-    assert err < 2e-3
+    # (PANDORA_CFG_BATCH=1: the unsharded run is then ONE forward over both clips - other grids, other split-K plans - and
+    # differs from the two sharded forwards at the bf16 level of the kernels, not bit for bit as the default two-stream form)
+    assert err < (1e-2 if os.environ.get("PANDORA_CFG_BATCH", "0") == "1" else 2e-3)
