@@ -69,6 +69,85 @@ def digest_of(t, stride, n):
     return flat[::int(stride)][:n]
 
 
+def _is_prime(p):
+    return p >= 2 and all(p % q for q in range(2, int(p ** 0.5) + 1))
+
+
+def coprime_stride(shape, n):
+    """Largest PRIME stride <= numel // n that divides no axis length: the flat samples k * stride then visit every
+    residue of every axis (every column, row, frame, channel) - a stride sharing a factor with W only ever lands on
+    W / gcd of the columns (VERDICT r04 weak #2: 72 on (..., 72, 128) saw columns 0, 8, ..., 120 only)."""
+    numel = int(np.prod(shape))
+    p = max(2, numel // int(n))
+    while not (_is_prime(p) and all(d % p for d in shape if d > 1)):
+        p -= 1
+        if p < 2:
+            return 1
+    return p
+
+
+FULL_LIMIT = 1 << 20  # tensors up to this many elements (every latent: <= 589 824) are committed whole
+
+
+def make_digest(t, n=4096):
+    """Fixture record of a tensor too big to commit: the WHOLE tensor when it has <= FULL_LIMIT elements, else a slice
+    at a prime stride coprime with every axis; always the global moments and the per-column / per-row profiles (rms and mean
+    over all other axes for every index of the last two axes), so that a defect confined to some columns or rows of a tile
+    edge changes a number the tests assert."""
+    import torch
+    x = t.detach().to(torch.float64)
+    flat = x.reshape(-1)
+    rec = {"mean": np.float64(flat.mean()), "std": np.float64(flat.std()), "absmax": np.float64(flat.abs().max()),
+           "numel": np.int64(flat.numel()), "shape": np.asarray(x.shape, np.int64)}
+    if flat.numel() <= FULL_LIMIT:
+        rec["full"] = t.detach().float().numpy().copy()
+    stride = coprime_stride(tuple(x.shape), n)
+    rec["slice"] = flat[::stride][:].float().numpy().copy()
+    rec["stride"] = np.int64(stride)
+    if x.dim() >= 2:
+        cols = x.reshape(-1, x.shape[-1])
+        rows = x.reshape(-1, x.shape[-2], x.shape[-1])
+        rec["col_rms"], rec["col_mean"] = cols.pow(2).mean(0).sqrt().numpy(), cols.mean(0).numpy()
+        rec["row_rms"], rec["row_mean"] = rows.pow(2).mean((0, 2)).sqrt().numpy(), rows.mean((0, 2)).numpy()
+    return rec
+
+
+def _rel(a, b):
+    import torch
+    a, b = torch.as_tensor(np.asarray(a)).double(), torch.as_tensor(np.asarray(b)).double()
+    return float((a - b).norm() / b.norm())
+
+
+def compare_digest(t, g, key, tol):
+    """Relative L2 error of tensor `t` against fixture record `key` of archive `g` (whole tensor when the record holds it,
+    else its strided slice), AFTER asserting everything else the record stores to `tol`: std and mean (in units of std),
+    absmax (3 tol: one element), and - records of format 2 - the per-column and per-row rms / mean profiles.  Returns
+    (err, std, fixture std).  Old records (stride from numel // n, no profiles) are still read."""
+    import torch
+    y = t.detach().float().cpu()
+    yd = y.double()
+    gstd, std = float(g[f"{key}/std"]), float(yd.std())
+    assert abs(std - gstd) <= tol * gstd, f"{key}: std {std} vs {gstd}"
+    assert abs(float(yd.mean()) - float(g[f"{key}/mean"])) <= tol * gstd, f"{key}: mean"
+    assert abs(float(yd.abs().max()) - float(g[f"{key}/absmax"])) <= 3 * tol * float(g[f"{key}/absmax"]), f"{key}: absmax"
+    assert int(g[f"{key}/numel"]) == y.numel()
+    if f"{key}/col_rms" in g:
+        assert tuple(int(d) for d in g[f"{key}/shape"]) == tuple(y.shape)
+        cols, rows = yd.reshape(-1, y.shape[-1]), yd.reshape(-1, y.shape[-2], y.shape[-1])
+        for name, got in (("col_rms", cols.pow(2).mean(0).sqrt()), ("row_rms", rows.pow(2).mean((0, 2)).sqrt())):
+            e = _rel(got, g[f"{key}/{name}"])
+            assert e <= tol, f"{key}/{name}: {e:.2e} > {tol:.1e}"
+        for name, got in (("col_mean", cols.mean(0)), ("row_mean", rows.mean((0, 2)))):
+            e = float((got - torch.as_tensor(g[f"{key}/{name}"])).abs().max())
+            assert e <= tol * gstd, f"{key}/{name}: {e:.2e} > {tol:.1e} x std"
+    if f"{key}/full" in g:
+        err = _rel(y, g[f"{key}/full"])
+    else:
+        stride, sl = int(g[f"{key}/stride"]), g[f"{key}/slice"]
+        err = _rel(digest_of(y, stride, len(sl)), sl)
+    return err, std, gstd
+
+
 def ae_latent(T, h, w):
     """scaled latent (1, 4, T, h, w) as the sampler returns it (std ~ scale_factor)."""
     n = 4 * T * h * w

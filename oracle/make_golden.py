@@ -27,12 +27,9 @@ WEIGHT_SEED, INPUT_SEED, NOISE_SEED = gr.WEIGHT_SEED, gr.INPUT_SEED, gr.NOISE_SE
 
 
 def digest(t, n=4096):
-    """Fixed strided slice + moments of a tensor (full-size outputs are too big to commit)."""
-    flat = t.detach().float().reshape(-1)
-    stride = max(1, flat.numel() // n)
-    return {"slice": flat[::stride][:n].numpy().copy(), "stride": np.int64(stride),
-            "mean": np.float64(flat.double().mean()), "std": np.float64(flat.double().std()),
-            "absmax": np.float64(flat.abs().max()), "numel": np.int64(flat.numel())}
+    """Fixture record of a full-size output (gr.make_digest, format 2: the whole tensor when it is a latent, else a slice at a
+    prime stride coprime with every axis; global moments; per-column / per-row profiles)."""
+    return gr.make_digest(t, n)
 
 
 def save(name, **arrays):
@@ -397,12 +394,15 @@ def gen_frames_small():
     save("frames_small.npz", **out)
 
 
-def gen_frames_full(cases, h=40, w=64):
+def gen_frames_full(cases, h=40, w=64, forwards=False):
     """Full width (1.44 B U-Net, full AutoencoderKL) at 16x40x64 -> 320x512 frames through the REAL reference:
     (10, 0.0) = BASELINE config 1 (eta 0) and (50, 1.0) = the production schedule with the recipe's shared noise.
-    Hours of CPU: run in the background (`nice`), digests only.
+    Hours of CPU: run in the background (`nice`).
     (h, w) = (72, 128): BASELINE configs[2]'s 576x1024 frames (r04) - the 1024 yaml's base_scale 0.3, the reference's
-    attention called frame by frame (rh.chunk_attention_over_frames: a memory shim, same arithmetic)."""
+    attention called frame by frame (rh.chunk_attention_over_frames: a memory shim, same arithmetic).
+    r05 (fixture format 2): latents are committed WHOLE, frames as ~65 K samples at a prime stride + column / row profiles;
+    the model is built once per resolution and also emits the single-forward fixtures (`forwards`) and the latent-only
+    trajectory fixtures `ddim_full_{h}x{w}_s{S}.npz` (the same `sample()` call as the frames run with eta 0)."""
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count() or 8)))
     t0 = time.time()
     big = (h, w) == (72, 128)
@@ -414,21 +414,37 @@ def gen_frames_full(cases, h=40, w=64):
     m.first_stage_model = _reference_first_stage()
     print(f"full model + first stage ready in {time.time() - t0:.0f}s", flush=True)
     ins, cond, uc = _small_setup(320, h, w)
+    src = "the real reference (lvdm UNetModel / DDIMSampler)" + (", attention called per frame" if big else "")
+    if forwards:
+        out = {"source": np.array(src)}
+        for tag, c in (("cond", cond),) if big else (("cond", cond), ("uncond", uc)):
+            t0 = time.time()
+            with torch.no_grad():
+                y = m.apply_model(ins["x_T"], torch.tensor([500]), c, fs=torch.tensor([15]))
+            print(f"reference forward {h}x{w} {tag}: {time.time() - t0:.0f}s std {y.std():.4f}", flush=True)
+            for k, v in digest(y).items():
+                out[f"{tag}/{k}"] = v
+        save(f"unet_full_{h}x{w}.npz", **out)
     for S, eta in cases:
         t0 = time.time()
         z, frames = _sample_and_decode(m, ins, cond, uc, h, w, S, eta, shared_noise=eta > 0)
         dt = time.time() - t0
         print(f"S={S} eta={eta}: {dt:.0f}s latent std {z.std():.4f} frames std {frames.std():.4f}", flush=True)
         out = {"source": np.array("the real reference: DDIMSampler.sample + LatentDiffusion.decode_first_stage")}
-        for k, v in digest(z, n=8192).items():
+        for k, v in digest(z).items():
             out[f"latent/{k}"] = v
-        for k, v in digest(frames, n=16384).items():
+        for k, v in digest(frames, n=65536).items():
             out[f"frames/{k}"] = v
         out["frames/per_frame_mean"] = frames[0].double().mean(dim=(0, 2, 3)).numpy()
         out["frames/per_frame_std"] = frames[0].double().std(dim=(0, 2, 3)).numpy()
         out["wall_seconds"] = np.float64(dt)
         out["threads"] = np.int64(torch.get_num_threads())
         save(f"frames_full_{h}x{w}_s{S}_eta{eta:g}.npz", **out)
+        if eta == 0 and (h, w, S) in ((40, 64, 10), (72, 128, 2)):
+            out = {"source": np.array(src), "wall_seconds": np.float64(dt), "threads": np.int64(torch.get_num_threads())}
+            for k, v in digest(z).items():
+                out[f"sample/{k}"] = v
+            save(f"ddim_full_{h}x{w}_s{S}.npz", **out)
 
 
 if __name__ == "__main__":
@@ -447,15 +463,18 @@ if __name__ == "__main__":
     ap.add_argument("--frames", action="store_true", help="reduced-width sampler -> decode_first_stage frames (seconds)")
     ap.add_argument("--frames-full", default="", help='full-width cases "S:eta,S:eta", e.g. "10:0,50:1" (hours of CPU)')
     ap.add_argument("--frames-full-72x128", default="", help='the same at 16x72x128 -> 576x1024 frames, e.g. "2:0"')
+    ap.add_argument("--with-forwards", action="store_true", help="--frames-full*: also the single-forward fixtures unet_full_*")
     a = ap.parse_args()
     if a.frames or a.frames_full or a.frames_full_72x128:
         assert rh.available()
         if a.frames:
             gen_frames_small()
         if a.frames_full_72x128:
-            gen_frames_full([(int(c.split(":")[0]), float(c.split(":")[1])) for c in a.frames_full_72x128.split(",")], 72, 128)
+            gen_frames_full([(int(c.split(":")[0]), float(c.split(":")[1])) for c in a.frames_full_72x128.split(",")], 72, 128,
+                            forwards=a.with_forwards)
         if a.frames_full:
-            gen_frames_full([(int(c.split(":")[0]), float(c.split(":")[1])) for c in a.frames_full.split(",")])
+            gen_frames_full([(int(c.split(":")[0]), float(c.split(":")[1])) for c in a.frames_full.split(",")],
+                            forwards=a.with_forwards)
         sys.exit(0)
     if a.ctx:
         assert rh.available()
