@@ -16,8 +16,8 @@
  *   - no allocation, no synchronisation, no exceptions: work is enqueued on `stream`
  *     (a hipStream_t passed as void*) and the call returns PM_OK (0) or a negative PM_E* code;
  *   - re-entrant: no mutable state between calls.  (Write-once process state only: per-device launch attributes
- *     and the CU count cached on first use, and the PANDORA_* tuning overrides - kernel choice / split-K threshold,
- *     never results - read from the environment once, before the first sizing query or launch.)
+ *     and the CU count, cached on first use.  This library reads NO environment variable: the PANDORA_* kernel-tuning
+ *     overrides exist only in the diagnostics build, include/pandora_mi355x_diag.h.)
  */
 #ifndef PANDORA_MI355X_H
 #define PANDORA_MI355X_H

@@ -57,7 +57,9 @@ class PackedWeights:
             named = list(self.named_parameters())
             step = max(1, len(named) // 40)
             mods = dict(self.named_modules())
-            sample = self._fp_sample = (len(named), [(mods[n.rpartition(".")[0]], n.rpartition(".")[2]) for n, _ in named[::step]])
+            # + every 0-dim parameter (CrossAttention.alpha): prepare() folds those into HOST scalars, nothing else would notice
+            picked = named[::step] + [(n, p) for i, (n, p) in enumerate(named) if p.dim() == 0 and i % step]
+            sample = self._fp_sample = (len(named), [(mods[n.rpartition(".")[0]], n.rpartition(".")[2]) for n, _ in picked])
         out = []
         for mod, leaf in sample[1]:
             p = getattr(mod, leaf)

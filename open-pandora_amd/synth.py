@@ -52,6 +52,8 @@ def synth_tensor(name, shape, seed, device="cpu"):
     if len(shape) >= 2:
         fan_in = n // shape[0]
         v = u * (3.0 ** 0.5) * (fan_in ** -0.5)
+    elif name.endswith("alpha"):   # learnable image-attention scale (256 yaml): tanh(alpha) + 1 well away from 1
+        v = 0.8 * u
     elif name.endswith("weight"):  # GroupNorm / LayerNorm scale
         v = 1.0 + 0.1 * u
     else:

@@ -51,7 +51,8 @@ def timestep_embedding(timesteps, dim, max_period=10000):
 # parameter containers: same attribute names / child indices as the reference modules
 # ------------------------------------------------------------------------------------------------
 class CrossAttention(nn.Module):
-    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, image_cross_attention=False):
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, image_cross_attention=False,
+                 image_cross_attention_scale_learnable=False):
         super().__init__()
         assert dim_head == 64, "the attention kernels are specialised for head dim 64"
         inner = heads * dim_head
@@ -66,6 +67,15 @@ class CrossAttention(nn.Module):
         if image_cross_attention:
             self.to_k_ip = nn.Linear(context_dim, inner, bias=False)
             self.to_v_ip = nn.Linear(context_dim, inner, bias=False)
+            # attention.py:77-78: the 256x256 checkpoint's per-block scalar; out + scale * out_ip * (tanh(alpha) + 1) (:139-140)
+            if image_cross_attention_scale_learnable:
+                self.register_parameter("alpha", nn.Parameter(torch.tensor(0.)))
+
+    def image_scale(self):
+        """Weight of the image branch (attention.py:138-142): image_cross_attention_scale (1.0 in every shipped yaml), times
+        tanh(alpha) + 1 when the scale is learnable."""
+        alpha = getattr(self, "alpha", None)
+        return 1.0 if alpha is None else 1.0 * (float(torch.tanh(alpha.detach().float())) + 1.0)
 
 
 class GEGLU(nn.Module):
@@ -81,18 +91,21 @@ class FeedForward(nn.Module):
 
 
 class BasicTransformerBlock(nn.Module):
-    def __init__(self, dim, n_heads, d_head, context_dim=None, image_cross_attention=False):
+    def __init__(self, dim, n_heads, d_head, context_dim=None, image_cross_attention=False,
+                 image_cross_attention_scale_learnable=False):
         super().__init__()
         self.attn1 = CrossAttention(dim, None, n_heads, d_head)
         self.ff = FeedForward(dim)
-        self.attn2 = CrossAttention(dim, context_dim, n_heads, d_head, image_cross_attention)
+        self.attn2 = CrossAttention(dim, context_dim, n_heads, d_head, image_cross_attention,
+                                    image_cross_attention_scale_learnable)
         self.norm1 = nn.LayerNorm(dim)
         self.norm2 = nn.LayerNorm(dim)
         self.norm3 = nn.LayerNorm(dim)
 
 
 class _Transformer(nn.Module):
-    def __init__(self, in_channels, n_heads, d_head, context_dim, use_linear, image_cross_attention, conv1d):
+    def __init__(self, in_channels, n_heads, d_head, context_dim, use_linear, image_cross_attention, conv1d,
+                 image_cross_attention_scale_learnable=False):
         super().__init__()
         inner = n_heads * d_head
         self.in_channels, self.inner, self.heads = in_channels, inner, n_heads
@@ -104,7 +117,8 @@ class _Transformer(nn.Module):
         else:
             self.proj_in = nn.Conv2d(in_channels, inner, kernel_size=1)
         self.transformer_blocks = nn.ModuleList(
-            [BasicTransformerBlock(inner, n_heads, d_head, context_dim, image_cross_attention)])
+            [BasicTransformerBlock(inner, n_heads, d_head, context_dim, image_cross_attention,
+                                   image_cross_attention_scale_learnable)])
         if use_linear:
             self.proj_out = nn.Linear(inner, in_channels)
         elif conv1d:
@@ -116,8 +130,10 @@ class _Transformer(nn.Module):
 
 
 class SpatialTransformer(_Transformer):
-    def __init__(self, in_channels, n_heads, d_head, context_dim, use_linear, image_cross_attention):
-        super().__init__(in_channels, n_heads, d_head, context_dim, use_linear, image_cross_attention, False)
+    def __init__(self, in_channels, n_heads, d_head, context_dim, use_linear, image_cross_attention,
+                 image_cross_attention_scale_learnable=False):
+        super().__init__(in_channels, n_heads, d_head, context_dim, use_linear, image_cross_attention, False,
+                         image_cross_attention_scale_learnable)
 
 
 class TemporalTransformer(_Transformer):
@@ -200,7 +216,6 @@ class UNetModel(packing.PackedWeights, nn.Module):
         _unsupported(tempspatial_aware, "tempspatial_aware")
         _unsupported(use_relative_position, "use_relative_position")
         _unsupported(use_causal_attention, "use_causal_attention")
-        _unsupported(image_cross_attention_scale_learnable, "image_cross_attention_scale_learnable")
         _unsupported(not temporal_selfatt_only, "temporal cross-attention")
         _unsupported(num_head_channels == -1, "num_heads without num_head_channels")
         self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
@@ -228,7 +243,8 @@ class UNetModel(packing.PackedWeights, nn.Module):
 
         def attn_layers(ch):
             heads = ch // num_head_channels
-            layers = [SpatialTransformer(ch, heads, num_head_channels, context_dim, use_linear, image_cross_attention)]
+            layers = [SpatialTransformer(ch, heads, num_head_channels, context_dim, use_linear, image_cross_attention,
+                                         image_cross_attention_scale_learnable)]
             if temporal_attention:
                 layers.append(TemporalTransformer(ch, heads, num_head_channels, use_linear))
             return layers
@@ -336,6 +352,7 @@ class UNetModel(packing.PackedWeights, nn.Module):
                     e["a2_kv"] = wt(torch.cat([a2.to_k.weight, a2.to_v.weight], 0))
                     if a2.image_cross_attention:
                         e["a2_kv_ip"] = wt(torch.cat([a2.to_k_ip.weight, a2.to_v_ip.weight], 0))
+                        e["a2_w2"] = a2.image_scale()  # host scalar (w2 of pm_attention), re-read with every re-pack
                 e["a2_out"] = lin(a2.to_out[0])
                 gw, gb = packing.pack_geglu(blk.ff.net[0].proj.weight.detach(), blk.ff.net[0].proj.bias.detach())
                 e["ff1"] = (wt(gw), f32(gb))
@@ -512,7 +529,7 @@ class UNetModel(packing.PackedWeights, nn.Module):
                     if kv_i is not None:
                         ki = kv_i[j:j + 1] if c.img_shared else kv_i[sl]
                         k2, v2 = ki[..., :inner], ki[..., inner:]
-                    got = ops.attention(q[sl], kv_t[j:j + 1, :, :inner], kv_t[j:j + 1, :, inner:], heads, k2, v2, 1.0,
+                    got = ops.attention(q[sl], kv_t[j:j + 1, :, :inner], kv_t[j:j + 1, :, inner:], heads, k2, v2, e.get("a2_w2", 1.0),
                                         out=None if a is None else a[sl])
                     a = got if a is None else a
             h = ops.gemm(a.view(F * P, inner), *e[f"a{which}_out"], residual=h, stream=True)

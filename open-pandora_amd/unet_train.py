@@ -45,7 +45,9 @@ def _cross_attention(mod, x, context=None):
     elif mod.image_cross_attention:
         text, img = context[:, :77], context[:, 77:]
         out = _attend(q, mod.to_k(text), mod.to_v(text), mod.heads)
-        out = out + 1.0 * _attend(q, mod.to_k_ip(img), mod.to_v_ip(img), mod.heads)
+        out_ip = _attend(q, mod.to_k_ip(img), mod.to_v_ip(img), mod.heads)
+        alpha = getattr(mod, "alpha", None)  # image_cross_attention_scale_learnable (attention.py:138-142): differentiable
+        out = out + (1.0 * out_ip if alpha is None else 1.0 * out_ip * (torch.tanh(alpha) + 1))
     else:
         # (attention.py:96-99: without image cross-attention the context is still cut at the text length)
         text = context[:, :77]

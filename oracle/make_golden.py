@@ -116,6 +116,35 @@ def gen_unet_small():
     save("unet_small.npz", **out)
 
 
+def gen_learnable():
+    """`image_cross_attention_scale_learnable` (attention.py:77-78,138-142; set by inference_256_v1.0.yaml:48): the real
+    CrossAttention with the per-block `alpha`, and the real UNetModel built from the 256 yaml's own unet_config (read from the
+    reference checkout, reduced to 64 base channels), seeded alphas well away from 0."""
+    import yaml
+    rh._install_shims()
+    from lvdm.modules.attention import CrossAttention
+    out = {}
+    mi = gr.module_inputs()
+    m = CrossAttention(128, 1024, heads=2, dim_head=64, image_cross_attention=True, video_length=16,
+                       image_cross_attention_scale_learnable=True).eval()
+    sd = synth.synth_state_dict(m, seed=WEIGHT_SEED)
+    assert "alpha" in sd and abs(float(sd["alpha"])) > 0.05
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        out["cross_attention_text_image_learnable"] = m(mi["tok"], context=mi["ctx"]).numpy()
+    with open(os.path.join(rh.REFERENCE_ROOT, "DynamiCrafter", "configs", "inference_256_v1.0.yaml")) as f:
+        kw = yaml.safe_load(f)["model"]["params"]["unet_config"]["params"]
+    assert all(kw[k] == v for k, v in gr.UNET_256_OVERRIDES.items())
+    tag, mc, h, w, t, fs = gr.UNET_SMALL_CASES[0]
+    ref = rh.reference_unet(**dict(kw, model_channels=mc, use_checkpoint=False))
+    ref.load_state_dict(synth.synth_state_dict(ref, seed=WEIGHT_SEED))
+    ins, _, _ = _small_setup(mc, h, w)
+    x = torch.cat([ins["x_T"], ins["c_concat"]], 1)
+    with torch.no_grad():
+        out["unet256/" + tag] = ref(x, torch.tensor([t]), context=ins["c_crossattn"], fs=torch.tensor([fs])).numpy()
+    save("unet_small_learnable.npz", **out)
+
+
 def gen_unet_ctx():
     """The `else` branch of UNetModel.forward's context handling (openaimodel3d.py:565-566): a context that is not
     77 + 16 t tokens long is repeated for every frame; CrossAttention still splits it at token 77."""
@@ -451,6 +480,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full-72x128", action="store_true")
     ap.add_argument("--ctx", action="store_true")
+    ap.add_argument("--learnable", action="store_true", help="image_cross_attention_scale_learnable fixtures (256 yaml)")
     ap.add_argument("--traj-72x128", type=int, default=0)
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--traj", action="store_true")
@@ -475,6 +505,10 @@ if __name__ == "__main__":
         if a.frames_full:
             gen_frames_full([(int(c.split(":")[0]), float(c.split(":")[1])) for c in a.frames_full.split(",")],
                             forwards=a.with_forwards)
+        sys.exit(0)
+    if a.learnable:
+        assert rh.available()
+        gen_learnable()
         sys.exit(0)
     if a.ctx:
         assert rh.available()

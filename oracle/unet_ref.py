@@ -101,7 +101,8 @@ def cross_attention(sd, x, context=None, text_len=77):
     v = _heads(_linear(sd, "to_v", ctx), h)
     out = _unheads(_softmax_attn(q, k, v, scale), h)
     if out_ip is not None:
-        out = out + 1.0 * out_ip  # image_cross_attention_scale = 1.0, not learnable (512/1024 yaml)
+        # image_cross_attention_scale = 1.0; learnable in the 256 yaml (attention.py:77-78,138-142): x (tanh(alpha) + 1)
+        out = out + (1.0 * out_ip * (torch.tanh(sd["alpha"].float()) + 1) if sd.has("alpha") else 1.0 * out_ip)
     return _linear(sd, "to_out.0", out)
 
 

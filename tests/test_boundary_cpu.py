@@ -52,6 +52,35 @@ def test_product_unet_behind_the_reference_shell_and_sampler():
 
 
 @needs_ref
+def test_shipped_256_yaml_unet_config_instantiates_the_product_unet():
+    """configs/inference_256_v1.0.yaml (the config BASELINE.md's 256x256 A100 number is quoted on) sets
+    `image_cross_attention_scale_learnable: true` (:48): its unet_config, verbatim, through the reference's own
+    instantiate_from_config with the product class as `target:` - full width on the meta device (key set = the reference
+    module's, the 16 `alpha` keys included), reduced width with weights against the real module's output."""
+    import yaml
+    rh._install_shims()
+    from utils.utils import instantiate_from_config
+    from lvdm.modules.networks.openaimodel3d import UNetModel as RefUNet
+    with open(os.path.join(rh.REFERENCE_ROOT, "DynamiCrafter", "configs", "inference_256_v1.0.yaml")) as f:
+        cfg = yaml.safe_load(f)["model"]["params"]["unet_config"]
+    with torch.device("meta"):
+        prod = instantiate_from_config(dict(cfg, target="open_pandora_amd.unet.UNetModel"))
+        ref = RefUNet(**cfg["params"])
+    assert type(prod) is UNetModel
+    ps, rs = prod.state_dict(), ref.state_dict()
+    assert set(ps) == set(rs) and all(ps[k].shape == rs[k].shape for k in rs)
+    assert sum(k.endswith(".alpha") for k in ps) == 16
+    small = instantiate_from_config(dict(target="open_pandora_amd.unet.UNetModel",
+                                         params=dict(cfg["params"], model_channels=64))).eval()
+    small.load_state_dict(synth.synth_state_dict(small, seed=gr.WEIGHT_SEED))
+    tag, mc, h, w, t, fs = gr.UNET_SMALL_CASES[0]
+    ins, _, _ = gr.sampler_inputs(h, w)
+    y = small.bind(TorchOps())(torch.cat([ins["x_T"], ins["c_concat"]], 1), torch.tensor([t]), context=ins["c_crossattn"],
+                               fs=torch.tensor([fs]))
+    assert rel(y, load("unet_small_learnable.npz")["unet256/" + tag]) < 2e-5
+
+
+@needs_ref
 def test_product_sampler_around_the_reference_shell():
     g = load("ddim_small.npz")[f"S{S}_eta{ETA:g}_cfg{CFG:g}"]
     ref = rh.reference_diffusion(dict(model_channels=64))

@@ -87,6 +87,37 @@ def test_modules_against_reference_classes():
         assert rel(got, g[name]) < 2e-5, (name, rel(got, g[name]))
 
 
+def test_learnable_image_attention_scale_against_reference():
+    """`image_cross_attention_scale_learnable` (attention.py:77-78,138-142; inference_256_v1.0.yaml:48): the oracle AND the
+    product graph on the oracle's op table against the REAL CrossAttention / the REAL UNetModel built from the 256 yaml's own
+    unet_config (oracle/make_golden.py --learnable); ignoring alpha must fail."""
+    from oracle.ops_torch import TorchOps
+    g = load("unet_small_learnable.npz")
+    mi = gr.module_inputs()
+    mod = U.CrossAttention(128, 1024, 2, 64, image_cross_attention=True, image_cross_attention_scale_learnable=True)
+    sd = _sd(mod)
+    assert "alpha" in sd and abs(float(sd["alpha"])) > 0.05
+    want = g["cross_attention_text_image_learnable"]
+    assert rel(unet_ref.cross_attention(_SD(sd), mi["tok"], mi["ctx"]), want) < 2e-5
+    assert rel(unet_ref.cross_attention(_SD({k: v for k, v in sd.items() if k != "alpha"}), mi["tok"], mi["ctx"]), want) > 1e-2
+    tag, mc, h, w, t, fs = gr.UNET_SMALL_CASES[0]
+    m = U.UNetModel(**dict(RH_KW, model_channels=mc, **gr.UNET_256_OVERRIDES)).eval()
+    sd = synth.synth_state_dict(m, seed=gr.WEIGHT_SEED)
+    assert sum(k.endswith("attn2.alpha") for k in sd) == 16  # one per SpatialTransformer, none in the temporal blocks
+    ins, _, _ = gr.sampler_inputs(h, w)
+    x = torch.cat([ins["x_T"], ins["c_concat"]], 1)
+    y = unet_ref.unet_forward(sd, x, torch.tensor([t]), ins["c_crossattn"], torch.tensor([fs]), model_channels=mc)
+    assert rel(y, g["unet256/" + tag]) < 2e-5
+    m.load_state_dict(sd)
+    y = m.bind(TorchOps())(x, torch.tensor([t]), context=ins["c_crossattn"], fs=torch.tensor([fs]))
+    assert rel(y, g["unet256/" + tag]) < 2e-5
+    with torch.no_grad():  # an in-place edit of alpha re-packs the host scalar (packing.PackedWeights fingerprint)
+        for k, prm in m.named_parameters():
+            if k.endswith("attn2.alpha"):
+                prm.zero_()
+    assert rel(m(x, torch.tensor([t]), context=ins["c_crossattn"], fs=torch.tensor([fs])), g["unet256/" + tag]) > 1e-3
+
+
 @pytest.mark.parametrize("tag,mc,h,w,t,fs", gr.UNET_SMALL_CASES)
 def test_unet_small_against_reference(tag, mc, h, w, t, fs):
     g = load("unet_small.npz")

@@ -52,6 +52,22 @@ def test_unet_small_forward(hip_ops_factory, dtype, tag, mc, h, w, t, fs):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_unet_small_forward_learnable_image_attention_scale(hip_ops_factory, dtype):
+    """The 256 yaml's U-Net (image_cross_attention_scale_learnable, attention.py:77-78,138-142): w2 = tanh(alpha) + 1 of
+    pm_attention's second segment, against the REAL module built from that yaml's unet_config at reduced width."""
+    tag, mc, h, w, t, fs = gr.UNET_SMALL_CASES[0]
+    g = load("unet_small_learnable.npz")["unet256/" + tag]
+    m = UNetModel(**dict(RH_KW, model_channels=mc, **gr.UNET_256_OVERRIDES)).eval()
+    m.load_state_dict(synth.synth_state_dict(m, seed=gr.WEIGHT_SEED))
+    ins, _, _ = gr.sampler_inputs(h, w)
+    x = torch.cat([ins["x_T"], ins["c_concat"]], 1).cuda()
+    y = m.bind(hip_ops_factory(dtype))(x, torch.tensor([t]).cuda(), context=ins["c_crossattn"].cuda(), fs=torch.tensor([fs]).cuda())
+    err = rel(y.cpu(), g)
+    print(f"\n[parity] unet_small 256-yaml (learnable image scale) {tag} {dtype}: rel err {err:.2e}")
+    assert err <= FWD_TOL_REDUCED[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_unet_small_forward_with_features_adapter(hip_ops_factory, dtype):
     """`features_adapter` (openaimodel3d.py:584-596) on the kernels: the plug-in features are added in place in the
     skip-concatenation buffers (stream AND skip), eagerly and inside a captured graph."""
