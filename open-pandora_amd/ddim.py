@@ -47,6 +47,26 @@ def make_ddim_timesteps(method, num_ddim, num_ddpm):
     raise NotImplementedError(f'There is no ddim discretization method called "{method}"')
 
 
+def _per_frame_kwargs(kwargs):
+    """Does a pass-through kwarg carry tensors sized for ONE clip (features_adapter: (T, C, H, W) per level)?"""
+    return any(torch.is_tensor(v) or (isinstance(v, (list, tuple)) and any(torch.is_tensor(w) for w in v)) for v in kwargs.values())
+
+
+def _cfg_batchable(ops, x, c, uc, kwargs, extra=()):
+    """PANDORA_CFG_BATCH=1 applies: ONE gate for the graph path and the eager path (the graph path skipped the
+    op table's capability check, and neither looked at kwargs - a features_adapter sized for T frames met a forward over 2 T
+    frames and failed the shape assert inside the capture).  Per-clip tensors in kwargs -> the two-forward form."""
+    return (uc is not None and not extra and os.environ.get("PANDORA_CFG_BATCH", "0") == "1" and isinstance(c, dict)
+            and isinstance(uc, dict) and set(c) == set(uc) and x.shape[0] == 1
+            and getattr(ops, "supports_batched_clips", True) and not _per_frame_kwargs(kwargs))
+
+
+def _version_of(v):
+    """In-place-edit counter for the graph keys; tensors created under torch.inference_mode() track none (reading
+    `_version` raises there) and cannot be edited in place outside it either: 0."""
+    return 0 if v.is_inference() else v._version
+
+
 class _ForwardGraph:
     """The U-Net forwards of one DDIM step (cond and, with CFG, uncond) captured once into a HIP graph
     and replayed every step: ~2000 kernel launches per step become one graph launch.  Inputs live in
@@ -58,7 +78,7 @@ class _ForwardGraph:
     levels) and each with a ramp and a tail; a second, independent chain fills those holes.
     (PANDORA_CFG_STREAMS=0: one stream, the two forwards in sequence.)"""
 
-    def __init__(self, model, x, t, c, uc, fs, kwargs, extra=()):
+    def __init__(self, model, x, t, c, uc, fs, kwargs, extra=(), ops=None):
         """`extra`: further condition sets whose forwards join the graph (the multi-condition sampler's third,
         image-only branch, ddim_multiplecond.py:232): captured on the main stream behind the conditional forward."""
         self.x = x.clone()
@@ -68,8 +88,7 @@ class _ForwardGraph:
         side, other = _capture_streams(dev)
         # PANDORA_CFG_BATCH=1: the cond / uncond pair as ONE forward over 2 x T frames (UNetModel batches the clips along the
         # rows: weights read once, grids twice as full) instead of two forwards on two streams
-        self.batched = (uc is not None and not extra and os.environ.get("PANDORA_CFG_BATCH", "0") == "1"
-                        and isinstance(c, dict) and set(c) == set(uc) and x.shape[0] == 1)
+        self.batched = _cfg_batchable(ops, x, c, uc, kwargs, extra)
         if self.batched:
             # static copies of the stacked conditions: the graph reads THESE at every replay, so they live as long as it does
             # (kept on self: as locals they were freed at the end of __init__ and the next eager allocation overwrote them)
@@ -277,7 +296,7 @@ class DDIMSampler:
         self._seg_probed = False
         self._gen = None  # multi-rank noise generator (see _draw)
 
-    def close(self):
+    def close(self, twin=True):
         """Release every captured graph of this sampler: the device drains, the graphs, the exchange closures recorded
         between them and their private memory pools go, the device drains again.  Call it before
         `dist.destroy_process_group()` (and before dropping the op table): the recorded exchanges hold RCCL-registered
@@ -288,6 +307,9 @@ class DDIMSampler:
         for g in self._graphs.values():
             g.close()
         self._graphs.clear()
+        other = getattr(self, "_multicond_twin", None)  # wm._multicond_sampler: the cached multi-condition sampler
+        if twin and other is not None:
+            other.close()
         import gc
         gc.collect()
         if torch.cuda.is_available() and torch.cuda.is_initialized():
@@ -427,14 +449,14 @@ class DDIMSampler:
                 tensors += [v] if torch.is_tensor(v) else [w for w in v if torch.is_tensor(w)] if isinstance(v, (list, tuple)) else []
             # (a weight reload / .to() re-packs the kernel-side weights: the captured graph holds raw pointers to the
             # old ones, so the U-Net's pack epoch is part of the key)
-            key = (tuple(x.shape), tuple((v.data_ptr(), tuple(v.shape), v._version) for v in tensors), tuple(sorted(kwargs)),
+            key = (tuple(x.shape), tuple((v.data_ptr(), tuple(v.shape), _version_of(v)) for v in tensors), tuple(sorted(kwargs)),
                    getattr(unet, "_pack_epoch", 0), os.environ.get("PANDORA_CFG_BATCH", "0"))
             g = self._graphs.get(key)
             if g is None:
                 for old in self._graphs.values():
                     old.close()
                 self._graphs.clear()  # one live graph: its private pool holds a forward's activations
-                g = self._graphs[key] = _ForwardGraph(self.model, x, t, cc, uu, fs, kwargs, extra)
+                g = self._graphs[key] = _ForwardGraph(self.model, x, t, cc, uu, fs, kwargs, extra, ops=ops)
             return g(x, t) + tuple(g.e_x)
 
         fp_u = getattr(unet, "fp", None)
@@ -460,7 +482,7 @@ class DDIMSampler:
                 tensors = [v for lst in cc.values() for v in lst] + ([fs] if torch.is_tensor(fs) else [])
                 # (the segments hold the peer mailbox's addresses by value: its generation is part of the key, ADVICE r03;
                 # read again after a recording, whose warm-up forward may have re-created the mailbox for a larger halo)
-                mk = lambda: ("seg", slot, tuple(x.shape), tuple((v.data_ptr(), tuple(v.shape)) for v in tensors),
+                mk = lambda: ("seg", slot, tuple(x.shape), tuple((v.data_ptr(), tuple(v.shape), _version_of(v)) for v in tensors),
                               tuple(sorted(kwargs)), getattr(unet, "_pack_epoch", 0),
                               getattr(getattr(fp_u, "mailbox", None), "generation", 0))
                 key = mk()
@@ -505,8 +527,7 @@ class DDIMSampler:
         elif fp_u is not None:
             e_c = forward_sharded(c, 0)
             e_u = forward_sharded(uc, 1) if use_cfg else None
-        elif (use_cfg and os.environ.get("PANDORA_CFG_BATCH", "0") == "1" and isinstance(c, dict) and set(c) == set(uc)
-              and x.shape[0] == 1 and getattr(ops, "supports_batched_clips", True)):
+        elif use_cfg and _cfg_batchable(ops, x, c, uc, kwargs):
             cc = {k: [torch.cat([a, b_], 0) for a, b_ in zip(c[k], uc[k])] for k in c}
             out = self.model.apply_model(torch.cat([x, x], 0), torch.cat([t, t], 0), cc, fs=fs, **kwargs)
             e_c, e_u = out[0:1], out[1:2]

@@ -658,8 +658,14 @@ class UNetModel(packing.PackedWeights, nn.Module):
                     if c.w["kv_img_all"] is not None and c.ctx_img is not None else None)
         # batched clips share ONE timestep (the CFG pair of a DDIM step): checked where that costs nothing - a host tensor;
         # a device tensor would need a synchronising read, which is illegal inside the sampler's graph capture
-        if b > 1 and timesteps.numel() > 1 and not timesteps.is_cuda and not bool((timesteps == timesteps.reshape(-1)[0]).all()):
-            raise NotImplementedError("batched clips share one timestep (the CFG pair of a DDIM step)")
+        # and fs likewise (_embed reads element 0 of both for every clip, so a batch with per-clip values used to
+        # get clip 0's embedding silently).  Device tensors are checked whenever a synchronising read is legal, i.e. outside a
+        # stream capture (the sampler's own batched call: t = cat([t, t]), validated on its warm-up forward).
+        if b > 1:
+            for name, v in (("timestep", timesteps), ("fs", fs)):
+                if torch.is_tensor(v) and v.numel() > 1 and not (v.is_cuda and torch.cuda.is_current_stream_capturing()):
+                    if not bool((v == v.reshape(-1)[0]).all()):
+                        raise NotImplementedError(f"batched clips share one {name} (the CFG pair of a DDIM step)")
         c.emb_bias = self._embed(c, timesteps, fs)
 
         xr = x.permute(1, 0, 2, 3, 4).reshape(cin, b * t, hh * ww)  # [C, (clip, frame), pixel]; a view for b == 1

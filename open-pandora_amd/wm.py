@@ -41,12 +41,16 @@ def _synthesize(diffusion_model, diffusion_conditioning, img_emb, uc_text_emb, u
                 sampler=None, **kwargs):
     """model.py:703-781 with the encoders factored out (private core of `DiffusionRunner.image_guided_synthesis`).
     Returns (batch, n_samples, c, t, h, w): decoded frames if `decode_first_stage` is given, else latents."""
+    temporary = None
     if multiple_cond_cfg:
         # model.py:705: the multi-condition sampler (SURVEY §8f row 4).  The reference's own class cannot run on this fork's
         # bf16 schedule buffers (ddim_multiplecond.py:40 raises TypeError: pinned by tests/test_oracle_vs_reference.py);
         # DDIMSamplerMultiCond is its working form (see that class), so the flag now does what model.py:737-743 intends
-        if not isinstance(sampler, DDIMSamplerMultiCond):
-            sampler = DDIMSamplerMultiCond(diffusion_model)
+        sampler, temporary = _multicond_sampler(diffusion_model, sampler)
+    elif sampler is not None:
+        twin = getattr(sampler, "_multicond_twin", None)
+        if twin is not None and twin._graphs:
+            twin.close()  # one graph pool (a forward's activations per branch) alive at a time
     sampler = sampler or DDIMSampler(diffusion_model)
     batch_size = noise_shape[0]
     dev = z_cond.device
@@ -61,15 +65,40 @@ def _synthesize(diffusion_model, diffusion_conditioning, img_emb, uc_text_emb, u
         uc_2 = {"c_crossattn": [torch.cat([uc_text_emb, img_emb], dim=1)], "c_concat": [z_cond]}
     kwargs.update({"unconditional_conditioning_img_nonetext": uc_2})
     variants = []
-    for _ in range(n_samples):  # independent replicas (model.py:749)
-        samples, _ = sampler.sample(S=ddim_steps, conditioning=cond, batch_size=batch_size, shape=noise_shape[1:],
-                                    verbose=kwargs.pop("verbose", False),
-                                    unconditional_guidance_scale=unconditional_guidance_scale,
-                                    unconditional_conditioning=uc, eta=ddim_eta, cfg_img=cfg_img, mask=None, x0=None,
-                                    fs=fs, timestep_spacing=timestep_spacing, guidance_rescale=guidance_rescale,
-                                    precision=diffusion_conditioning.dtype, **kwargs)
-        variants.append(decode_first_stage(samples) if decode_first_stage is not None else samples)
+    try:
+        for _ in range(n_samples):  # independent replicas (model.py:749)
+            samples, _ = sampler.sample(S=ddim_steps, conditioning=cond, batch_size=batch_size, shape=noise_shape[1:],
+                                        verbose=kwargs.pop("verbose", False),
+                                        unconditional_guidance_scale=unconditional_guidance_scale,
+                                        unconditional_conditioning=uc, eta=ddim_eta, cfg_img=cfg_img, mask=None, x0=None,
+                                        fs=fs, timestep_spacing=timestep_spacing, guidance_rescale=guidance_rescale,
+                                        precision=diffusion_conditioning.dtype, **kwargs)
+            variants.append(decode_first_stage(samples) if decode_first_stage is not None else samples)
+    finally:
+        if temporary is not None:
+            temporary.close()  # (built for this call only: its three-forward graph and pool go with it)
     return torch.stack(variants).permute(1, 0, 2, 3, 4, 5)
+
+
+def _multicond_sampler(diffusion_model, sampler):
+    """The DDIMSamplerMultiCond to use where the caller holds a plain DDIMSampler: ONE twin per sampler, built
+    with that sampler's own op table, graph switch and CFG-pair object - so a multi-rank deployment reaches the twin's
+    NotImplementedError guard instead of sampling unsynchronised noise per rank - cached on it (one warm-up and one
+    three-forward capture per configuration, not per call) and closed with it.  The primary's graphs are released first:
+    two pools would hold two sets of a forward's activations.  -> (sampler, temporary or None)."""
+    if isinstance(sampler, DDIMSamplerMultiCond):
+        return sampler, None
+    if sampler is None:
+        tmp = DDIMSamplerMultiCond(diffusion_model)
+        return tmp, tmp
+    twin = getattr(sampler, "_multicond_twin", None)
+    if twin is None or twin.model is not sampler.model:
+        twin = DDIMSamplerMultiCond(sampler.model, schedule=sampler.schedule, use_graph=sampler.use_graph,
+                                    cfg_parallel=sampler.cfg_parallel, ops=sampler._ops_override)
+        sampler._multicond_twin = twin
+    if sampler._graphs:
+        sampler.close(twin=False)
+    return twin, None
 
 
 class ImageContext:

@@ -36,6 +36,8 @@ def test_batched_forward_equals_two_forwards(L):
         assert rel(ya, load("unet_small.npz")["mc64_8x8_t500"]) < 2e-5  # (and it is still the reference's forward)
     with pytest.raises(NotImplementedError):
         m(torch.cat([x, x], 0), torch.tensor([500, 499]), context=torch.cat([ca, cb], 0), fs=fs)
+    with pytest.raises(NotImplementedError):  # per-clip fs used to get clip 0's embedding silently
+        m(torch.cat([x, x], 0), torch.cat([t, t]), context=torch.cat([ca, cb], 0), fs=torch.tensor([15, 24]))
 
 
 def test_sampler_in_batch_mode_equals_the_reference_trajectory(monkeypatch):
@@ -52,3 +54,30 @@ def test_sampler_in_batch_mode_equals_the_reference_trajectory(monkeypatch):
                                   fs=torch.tensor([15]), timestep_spacing="uniform_trailing", x_T=ins["x_T"])
     assert shapes == [(2, 4, 16, 8, 8)] * S  # ONE forward per step
     assert rel(y, g) < 5e-5
+
+
+def test_batch_mode_falls_back_to_two_forwards_for_per_clip_kwargs_and_inference_tensors(monkeypatch):
+    """(i) PANDORA_CFG_BATCH=1 with a features_adapter sized for ONE clip keeps the two-forward form (a forward
+    over 2 T frames would fail the adapter's shape assert); (ii) conditions created under torch.inference_mode() have no
+    version counter - the graph-key recipe must not read it."""
+    from open_pandora_amd import ddim
+    m = _model()
+    pm = LatentVisualDiffusion(m)
+    ins, cond, uc = gr.sampler_inputs(8, 8)
+    feats = gr.adapter_features(64, 8, 8)
+    monkeypatch.setenv("PANDORA_CFG_BATCH", "1")
+    assert ddim._cfg_batchable(m.ops, ins["x_T"], cond, uc, {})
+    assert not ddim._cfg_batchable(m.ops, ins["x_T"], cond, uc, {"features_adapter": feats})
+    shapes = []
+    inner = pm.apply_model
+    pm.apply_model = lambda x, t, c, **kw: (shapes.append(tuple(x.shape)), inner(x, t, c, **kw))[1]
+    kw = dict(S=2, batch_size=1, shape=(4, 16, 8, 8), conditioning=cond, verbose=False, unconditional_guidance_scale=4.0,
+              unconditional_conditioning=uc, eta=0.0, fs=torch.tensor([15]), timestep_spacing="uniform_trailing", x_T=ins["x_T"])
+    ya, _ = DDIMSampler(pm).sample(features_adapter=feats, **kw)
+    assert shapes == [(1, 4, 16, 8, 8)] * 4
+    monkeypatch.setenv("PANDORA_CFG_BATCH", "0")
+    yb, _ = DDIMSampler(pm).sample(features_adapter=feats, **kw)
+    assert torch.equal(ya, yb)
+    with torch.inference_mode():
+        v = torch.ones(3)
+    assert ddim._version_of(v) == 0 and ddim._version_of(torch.ones(3)) == 0

@@ -145,7 +145,7 @@ def test_frames_full_width_parity_mode(res, h, w, S, tol):
 FRAMES_FP8_576_TOL = 1.1e-2  # measured 8.2e-3 (latent 7.4e-3); f16 without fp8: 2.3e-3 / parity mode 1.7e-3 on the same fixture
 
 
-def test_frames_full_width_576x1024_fp8_attention_selective():
+def test_frames_full_width_576x1024_fp8_attention_selective(monkeypatch):
     path = os.path.join(GOLD, "frames_full_72x128_s2_eta0.npz")
     if not os.path.exists(path):
         pytest.skip("frames_full_72x128_s2_eta0.npz not generated yet (oracle/make_golden.py --frames-full-72x128 2:0)")
@@ -158,11 +158,8 @@ def test_frames_full_width_576x1024_fp8_attention_selective():
     ops.attention_fp8 = lambda *a, **k: (calls.__setitem__("fp8", calls["fp8"] + 1), fp8_inner(*a, **k))[1]
     ops.attention = lambda *a, **k: (calls.__setitem__("f16", calls["f16"] + 1), att_inner(*a, **k))[1]
     pm = factory.build_diffusion("576x1024", ops, seed=gr.WEIGHT_SEED)
-    os.environ["PANDORA_HIPGRAPH"] = "0"  # (eager: the call counters above see every forward)
-    try:
-        z = _sample(pm, 72, 128, 2, 0.0)
-    finally:
-        os.environ.pop("PANDORA_HIPGRAPH", None)
+    monkeypatch.setenv("PANDORA_HIPGRAPH", "0")  # (eager: the call counters above see every forward; restored by pytest -
+    z = _sample(pm, 72, 128, 2, 0.0)              #  an externally set value survives this test)
     # per forward: 10 spatial self-attentions on fp8 (levels 0 and 1: 5 + 5), 6 (levels 2, 3 + middle) and the 16 cross-attentions on f16
     if os.environ.get("PANDORA_CFG_BATCH", "0") == "1":  # one forward over both clips per step, cross-attention per clip
         assert calls["fp8"] == 10 * 2 and calls["f16"] == (6 + 16 * 2) * 2, calls

@@ -101,3 +101,27 @@ def test_multiple_cond_cfg_selects_the_three_forward_sampler():
     wm._synthesize(pm, text, img, uct, uci, ins["c_concat"], (1, 4, 16, 8, 8), n_samples=1, ddim_steps=2, ddim_eta=0.0,
                    unconditional_guidance_scale=cfg, fs=15, timestep_spacing="uniform_trailing", x_T=ins["x_T"])
     assert len(calls) == 2 * 2
+
+
+def test_multicond_twin_is_cached_configured_like_the_callers_sampler_and_closed_with_it():
+    """with `multiple_cond_cfg=True` and a plain DDIMSampler passed in (what DiffusionRunner does), ONE
+    DDIMSamplerMultiCond is built from that sampler's op table / graph switch / CFG-pair object and cached on it - not a fresh
+    default-configured sampler (fresh warm-up + capture, leaked pool, multi-rank guard bypassed) per call."""
+    from open_pandora_amd.ddim import DDIMSampler, DDIMSamplerMultiCond
+    m = UNetModel(**dict(RH_KW, model_channels=64)).eval()
+    pm = LatentVisualDiffusion(m.bind(TorchOps()))
+    ops2, pair = TorchOps(), object()
+    primary = DDIMSampler(pm, use_graph=False, cfg_parallel=pair, ops=ops2)
+    twin, tmp = wm._multicond_sampler(pm, primary)
+    assert isinstance(twin, DDIMSamplerMultiCond) and tmp is None
+    assert twin.use_graph is False and twin.cfg_parallel is pair and twin._ops_override is ops2 and twin.model is pm
+    assert wm._multicond_sampler(pm, primary)[0] is twin                      # cached: one per sampler
+    assert wm._multicond_sampler(pm, twin) == (twin, None)                    # already the right class: used as is
+    t2, tmp2 = wm._multicond_sampler(pm, None)                                # no sampler: a temporary, closed by the caller
+    assert tmp2 is t2 and t2 is not twin
+    closed = []
+    twin.close = lambda *a, **k: closed.append("twin")
+    primary.close()
+    assert closed == ["twin"]
+    # a CFG-pair deployment reaches the multi-condition sampler's own guard instead of sampling per-rank noise
+    assert twin._multi_rank()
