@@ -371,6 +371,13 @@ def main():
                     help="HipOps(parity=True): every GroupNorm / LayerNorm output as [hi | lo] 16-bit parts (2x the MFMA work on the "
                          "ops they feed) - the configuration whose FRAMES meet the north-star's 1e-3 (tests/test_frames_gpu.py); "
                          "use with --dtype f16: its step time goes on record next to the bf16 production number")
+    ap.add_argument("--split", default="hybrid", choices=["hybrid", "frames-kv"],
+                    help="N > 1: 'hybrid' = cond / uncond branch pair x N/2 frame shards, temporal blocks re-sharded frames <-> pixels "
+                         "(frame_parallel.make_hybrid's default); 'frames-kv' = the north-star's literal split - N frame shards, "
+                         "both branches per rank, K|V all-gather for the temporal attention")
+    ap.add_argument("--rehearsal-width", type=int, default=0, help=argparse.SUPPRESS)  # (functional rehearsals of the N > 1 code
+    #   path on ONE GPU, tests/test_bench_rehearsal_gpu.py: a U-Net of that many base channels; the line says so and is not a
+    #   measurement of the named model)
     a = ap.parse_args()
     only = a.only or a.res
 
@@ -396,7 +403,8 @@ def main():
 
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     ops = TimedOps(HipOps(dt, dev, fp8_attention=a.fp8_attention, parity=a.parity))
-    pm0 = factory.build_diffusion("320x512", ops)  # the two shipped configs share the U-Net (1 516 tensors)
+    pm0 = factory.build_diffusion("320x512", ops,  # the two shipped configs share the U-Net (1 516 tensors)
+                                  unet_overrides=dict(model_channels=a.rehearsal_width) if a.rehearsal_width else None)
     unet = pm0.model.diffusion_model
     fp = cfgp = None
     mode = "1 GPU"
@@ -404,7 +412,8 @@ def main():
         from open_pandora_amd.frame_parallel import make_hybrid
         # peer mailboxes sized once for the largest boundary frame of the run (f32 [72*128, 320]): no re-creation between
         # the two resolutions, whose recorded graphs hold the mailbox addresses
-        fp, cfgp = make_hybrid(T, ops=ops, halo_bytes=4 * 72 * 128 * 320)
+        fp, cfgp = make_hybrid(T, ops=ops, halo_bytes=4 * 72 * 128 * 320,
+                               **(dict(use_cfg=False, kv_gather=True) if a.split == "frames-kv" else {}))
         unet.bind(ops, fp)
         fw = 1 if fp is None else fp.world
         mode = (f"{'cond/uncond branch pair x ' if cfgp is not None else ''}{fw}-way frame shards "
@@ -681,7 +690,10 @@ def main():
             out["config"]["numerics"] = ("HipOps(parity=True): norm outputs carried as [hi | lo] 16-bit parts (the 1e-3-frames "
                                          "configuration, tests/test_frames_gpu.py::test_frames_*_parity_mode)")
         if world > 1:
-            out["multi_gpu"] = multi_gpu
+            out["multi_gpu"] = dict(multi_gpu, split=a.split)
+        if a.rehearsal_width:
+            out["rehearsal"] = f"U-Net of {a.rehearsal_width} base channels: a functional rehearsal, NOT a measurement of the named model"
+            out["value"] = None
         if a.fp8_attention:
             out["config"]["attention"] = "fp8 (e4m3) operands on v_mfma_scale_f32_32x32x64_f8f6f4 for the spatial self-attention"
         if multi is not None:

@@ -1287,6 +1287,7 @@ static int g_num_cus[MAX_DEVICES] = {0};
 static int g_natural = 1;          // PANDORA_GEMM_NATURAL (diagnostics build): 0 = interleaved W rows for the f32 flavours too (A/B)
 static int g_persist_per_cu = 0;    // PANDORA_GEMM_PERSIST: persistent 2-stage workgroups per CU (0 = one work item per workgroup; measured: 2/CU = no gain, 1 or 3/CU 5 % slower)
 static int g_split_min_nk = 24;     // PANDORA_SPLITK_MIN_NK: shortest K loop (in 64-wide tiles) that is split
+static int g_split_max_tiles = 384; // PANDORA_SPLITK_MAX_TILES: grids of at least this many tiles never split
 static int g_split_model = 1;       // PANDORA_SPLITK_MODEL: 0 = the round-1 rule (aim at 512 work items), for A/B runs
 static int g_split_force = 0;       // PANDORA_SPLITK_FORCE = s > 0: every splittable call takes (up to) s slices (sweeps that fit the model)
 
@@ -1303,6 +1304,8 @@ static void init_once() {
   static const bool init = [] {
     const char* m = diag_env("PANDORA_SPLITK_MIN_NK");
     if (m) g_split_min_nk = atoi(m);
+    const char* mt = diag_env("PANDORA_SPLITK_MAX_TILES");
+    if (mt) g_split_max_tiles = atoi(mt);
     const char* rwe = diag_env("PANDORA_GEMM_RINGW");
     if (rwe) g_ringw = atoi(rwe);
     const char* r = diag_env("PANDORA_GEMM_RING");
@@ -1334,7 +1337,7 @@ static int choose_splits(int64_t M, int64_t N, int64_t K, int act, int* ktps, bo
   const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   const int nk = (int)((K + BK - 1) / BK);
   *ktps = nk;
-  if (act == PM_ACT_GEGLU || tiles >= 384 || nk < g_split_min_nk) return 1;
+  if (act == PM_ACT_GEGLU || tiles >= g_split_max_tiles || nk < g_split_min_nk) return 1;
   if (g_split_force > 0) {
     int s = g_split_force;
     if (s > nk / 4) s = nk / 4;

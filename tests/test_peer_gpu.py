@@ -43,7 +43,7 @@ def _stats(rank, it, n):
     return torch.randn(n, generator=g)
 
 
-def _unit_worker(rank, world, port, out):
+def _unit_worker(rank, world, port, out, n_eager=40, n_replay=8):
     _init(rank, world, port)
     try:
         from open_pandora_amd.frame_parallel import FrameParallel
@@ -54,7 +54,7 @@ def _unit_worker(rank, world, port, out):
         assert mb is not None
         log = []
         shapes = [(256, 96), (64, 320), (16, 640), (256, 96), (4, 1280), (64, 320)]  # the largest comes first, as in the U-Net
-        for it in range(40):
+        for it in range(n_eager):
             P, C = shapes[it % len(shapes)]
             n = (64, 64, 128, 32)[it % 4]
             st = _stats(rank, it, n).cuda()
@@ -84,7 +84,7 @@ def _unit_worker(rank, world, port, out):
             t2, _, _ = mb.exchange(t1 * 0.5)  # a dependent, statistics-only exchange in the same graph
             t3, lo3, hi3 = mb.exchange(s_in + 1.0, l_in, f_in)
         glog = []
-        for it in range(100, 108):
+        for it in range(100, 100 + n_replay):
             s_in.copy_(_stats(rank, it, n)), f_in.copy_(_frame(rank, it, P, C, 0)), l_in.copy_(_frame(rank, it, P, C, 1))
             g.replay()
             torch.cuda.synchronize()
@@ -110,17 +110,20 @@ def _unit_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("world", [2, 4])
-def test_peer_mailbox_exchange_unit(tmp_path, world):
+# world 8 = the configuration the north-star names (BASELINE configs[3]-[4]): 7 hipIpc handles mapped per rank, sums from 7
+# peers counted per exchange, halo frames to both neighbours of ranks 1..6.  Eight processes time-slice the ONE GPU, so every
+# exchange costs a scheduling quantum per rank: a handful of exchanges (all six shapes, both kinds, one replayed graph twice).
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,n_eager,n_replay", [(2, 40, 8), (4, 40, 8), (8, 12, 2)])
+def test_peer_mailbox_exchange_unit(tmp_path, world, n_eager, n_replay):
     out = str(tmp_path / "u.pt")
-    mp.spawn(_unit_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_unit_worker, args=(world, _free_port(), out, n_eager, n_replay), nprocs=world, join=True)
     for r in range(world):
         got = torch.load(f"{out}.{r}")
-        assert all(got["log"]), (r, got["log"])
-        assert all(got["glog"]), (r, got["glog"])
-        assert got["epoch"] == 40 + 3 * 8  # every exchange closed its slot (the capture itself launches nothing)
-        print(f"\n[parity] peer mailbox world={world} rank {r}: 40 eager + 24 replayed exchanges bit-exact "
+        assert len(got["log"]) == n_eager and all(got["log"]), (r, got["log"])
+        assert len(got["glog"]) == n_replay and all(got["glog"]), (r, got["glog"])
+        assert got["epoch"] == n_eager + 3 * n_replay  # every exchange closed its slot (the capture itself launches nothing)
+        print(f"\n[parity] peer mailbox world={world} rank {r}: {n_eager} eager + {3 * n_replay} replayed exchanges bit-exact "
               f"(fine-grained memory: {got['fine_grained']})")
 
 
