@@ -20,6 +20,18 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+# parity="selective": the sites whose [hi | lo] operands buy the error, from the leave-one-out table of tools/parity_sites.py
+# (profiles/r05/parity_sites_320x512_leave_one_out.txt: full-width 10-step CFG-4 FRAMES against the real reference with each
+# (kind, level) class taken out of the full parity configuration, and the step time it costs).  The error the [hi | lo]
+# operands remove sits at the shallow levels - every transformer's GroupNorm -> proj_in (all of it for 0.5 ms), the f32
+# stream into Downsample / Upsample / stem convs, the level-0/1 GroupNorm -> 3x3 conv, the level-0 temporal sites; the
+# LayerNorm -> q|k|v / q / GEGLU projections of the SPATIAL blocks and everything at the 1280-channel levels buy nothing
+# measurable and keep their one-rounding operands (and the fused LayerNorm + projection kernel).
+SELECTIVE_PARITY_SITES = frozenset(
+    [("gnp", lv) for lv in range(4)] + [("split", lv) for lv in range(3)] + [("gn3", 0), ("gn3", 1), ("gnt", 0), ("gnt", 2),
+                                                                            ("lnt1", 0), ("lnt2", 0), ("lnt3", 0)])
+
+
 class HipOps:
     name = "hip"
     supports_graphs = True  # every op only enqueues kernels on the current stream: capturable
@@ -52,8 +64,20 @@ class HipOps:
         # written as [hi | lo] (PM_OUT_HILO) and consumed over 2C channels with the weights walked twice (PM_FLAG_W_WRAP
         # for dense GEMMs, repeated packed weights for the 3x3 / temporal convs); the f32 stream entering Downsample /
         # Upsample convs likewise.  Twice the MFMA work on those ops: a numerics mode, not a performance mode.
+        # parity=True: every site.  parity="selective" / a collection of (kind, level) sites (UNetModel._site names the site of
+        # the next call in `self.site`): only those - the rest keep the one-rounding operands AND the fused LayerNorm +
+        # projection kernel; calls outside the U-Net (first stage, Resampler: `site` None) take [hi | lo] whenever parity is on.
+        self.site = None
+        self.parity_sites = None
+        if isinstance(parity, str):
+            if parity != "selective":
+                raise ValueError(f"parity={parity!r}: True, False, 'selective' or a collection of (kind, level) sites")
+            parity = SELECTIVE_PARITY_SITES
+        if not isinstance(parity, bool) and parity is not None:
+            self.parity_sites = frozenset((str(k), int(lv)) for k, lv in parity)
+            parity = True
         self.parity = bool(parity)
-        if self.parity:
+        if self.parity and self.parity_sites is None:
             self.fused_ln = False  # (the panel kernel keeps its normalised panel as 16 bit in LDS)
         self._dup = {}  # parity: packed conv weights with every tap's channel block repeated, keyed by (data_ptr, taps)
         self.dtype = dtype
@@ -72,6 +96,12 @@ class HipOps:
         self._workspaces = {}
 
     # -- helpers ---------------------------------------------------------------------------------
+    def _hilo(self):
+        """Is the norm / conversion output of the CURRENT site carried as [hi | lo]?  (see `parity` in __init__)"""
+        if not self.parity:
+            return False
+        return self.parity_sites is None or self.site is None or self.site in self.parity_sites
+
     def _stream(self):
         # raw handle of torch's current stream on this device; the C getter avoids building a Stream object
         # per launch (a quarter of the host-side cost of an eagerly launched forward, tools/host_profile.py)
@@ -227,10 +257,10 @@ class HipOps:
                 # Upsample.conv (openaimodel3d.py:96-108): the nearest x2 interpolation is written out by the conversion pass
                 # (4x the 16-bit bytes, once) and the conv runs in the FAST 3x3 mode on the DMA-staged ring kernels instead of
                 # gathering the upsampled pixels per lane in the general mode
-                x = self.split16_upsample2x(x, F, H, W, with_lo=self.parity)
+                x = self.split16_upsample2x(x, F, H, W, with_lo=self._hilo())
                 H, W, upsample = 2 * H, 2 * W, False
             else:
-                x = self.split16(x, with_lo=self.parity)  # the f32 stream (Downsample / Upsample): rounded once here, then the DMA loaders
+                x = self.split16(x, with_lo=self._hilo())  # the f32 stream (Downsample / Upsample): rounded once here, then the DMA loaders
             # (pm_split16 moves 8-element chunks: other widths keep the register-staged f32 loader)
         if x.shape[1] * 9 == 2 * wp.shape[1]:
             wp = self._repeat_taps(wp, 9)  # [hi | lo] input: the same weights for both halves of every tap
@@ -313,7 +343,7 @@ class HipOps:
         if count is None:
             count = float(P * (C // groups))
         odt = self.dt
-        if self.parity and out is None:
+        if self._hilo() and out is None:
             out, odt = self.empty(M, 2 * C), self.dt | capi.PM_OUT_HILO  # [hi | lo]
         if out is None:
             out = self.empty(M, C)
@@ -339,7 +369,7 @@ class HipOps:
     def layernorm(self, x, gamma, beta, eps=1e-5, out=None):
         M, C = x.shape
         odt = self.dt
-        if self.parity and out is None:
+        if self._hilo() and out is None:
             out, odt = self.empty(M, 2 * C), self.dt | capi.PM_OUT_HILO  # [hi | lo]
         if out is None:
             out = self.empty(M, C)
@@ -356,7 +386,7 @@ class HipOps:
         M, K = x.shape
         N = w.shape[0]
         code = capi.ACT_CODES[act]
-        if (self.fused_ln and x.dtype == torch.float32 and code in (capi.PM_ACT_NONE, capi.PM_ACT_GEGLU)
+        if (self.fused_ln and not self._hilo() and x.dtype == torch.float32 and code in (capi.PM_ACT_NONE, capi.PM_ACT_GEGLU)
                 and self.lib.pm_ln_gemm_supported(M, N, K, code)):
             assert w.shape[1] == K and w.is_contiguous() and w.dtype == self.dtype and x.stride(1) == 1
             flags = 0

@@ -195,7 +195,7 @@ class TimestepEmbedSequential(nn.Sequential):
 class _Ctx:
     """Per-forward execution state."""
     __slots__ = ("ops", "fp", "F", "H", "W", "emb_bias", "ctx_text", "ctx_img", "w", "stats", "kv_text", "kv_img",
-                 "img_shared", "B", "T")  # B clips of T frames each batched along the rows: F = B * T (B = 1: the reference's call)
+                 "img_shared", "B", "T", "H0", "level0")  # B clips of T frames each batched along the rows: F = B * T (B = 1: the reference's call)
 
 
 class UNetModel(packing.PackedWeights, nn.Module):
@@ -387,9 +387,19 @@ class UNetModel(packing.PackedWeights, nn.Module):
         return self
 
     # ---- graph ---------------------------------------------------------------------------------
+    @staticmethod
+    def _site(c, kind):
+        """Name the norm / conversion site the next op-table call belongs to: (kind, pyramid level).  An op table that carries
+        selected norm outputs at twice the mantissa (HipOps(parity="selective" | {...})) decides per
+        site; others ignore the attribute.  Kinds: gn3 / gnt = GroupNorm + SiLU in front of a 3x3 / temporal conv, gnp = the
+        transformers' GroupNorm in front of proj_in, lns1 / lns2 / lns3 (lnt*) = LayerNorm in front of the spatial (temporal)
+        block's attn1 projection / attn2 projection / GEGLU, split = the f32 stream into a Downsample / Upsample / stem conv."""
+        c.ops.site = (kind, c.level0 + (c.H0 // max(1, c.H)).bit_length() - 1)
+
     def _gn(self, c, x, gb, eps, silu, per_frame, totals=None):
         """`totals`: {sum, sumsq} already produced by the epilogue of the op that wrote x."""
         ops = c.ops
+        self._site(c, ("gn3" if per_frame else "gnt") if silu else "gnp")
         if totals is None:  # statistics a previous module's last op left behind ON this very tensor object
             tot = getattr(x, "_pm_gn_totals", None)
             if tot is not None:
@@ -494,6 +504,7 @@ class UNetModel(packing.PackedWeights, nn.Module):
             key = f"a{which}_qkv"
             if key in e:  # self-attention, fused q|k|v projection
                 qs = e.get("a1_qscale") if which == 1 else None
+                self._site(c, f"ln{'t' if temporal else 's'}{which}")
                 qkv = v3(ops.ln_gemm(h, *ln, e[key], col_scale=qs), 3 * inner)
                 q, k, v = qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:]
                 if temporal:
@@ -513,6 +524,7 @@ class UNetModel(packing.PackedWeights, nn.Module):
                 else:
                     a = ops.attention(q, k, v, heads)
             else:  # spatial cross-attention: text keys shared by all frames + per-frame image keys
+                self._site(c, "lns2")
                 q = v3(ops.ln_gemm(h, *ln, e["a2_q"]), inner)
                 lo, hi = e["a2_kv_slice"]
                 kv_t = c.kv_text[:, lo:hi].unflatten(0, (c.B, -1))  # [B, 77, 2*inner] view of the batched projection
@@ -533,6 +545,7 @@ class UNetModel(packing.PackedWeights, nn.Module):
                                         out=None if a is None else a[sl])
                     a = got if a is None else a
             h = ops.gemm(a.view(F * P, inner), *e[f"a{which}_out"], residual=h, stream=True)
+        self._site(c, f"ln{'t' if temporal else 's'}3")
         g = ops.ln_gemm(h, *e["ln3"], e["ff1"][0], e["ff1"][1], act="geglu")
         # the block's last add: its only consumer is proj_out's A operand (16-bit anyway), so the sum
         # (formed in f32 against the f32 stream) is stored as 16 bit
@@ -568,6 +581,7 @@ class UNetModel(packing.PackedWeights, nn.Module):
                 h = self._transformer(c, layer, h, True, dst)
             elif isinstance(layer, Downsample):
                 wp, b = c.w[self._names[layer]]
+                self._site(c, "split")
                 h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W, stride=2, stream=True, out=dst)
                 c.H, c.W = (c.H + 1) // 2, (c.W + 1) // 2
             elif isinstance(layer, Upsample):
@@ -575,10 +589,12 @@ class UNetModel(packing.PackedWeights, nn.Module):
                 # (r03 kept the gathered form for frame shards because tests/test_segmented_gpu.py aborted with the written-out
                 # interpolation; the abort was the process group's watchdog querying an event of a capturing stream -
                 # frame_parallel.FrameParallel._comm - and had nothing to do with this op: one form everywhere again)
+                self._site(c, "split")
                 h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W, upsample=True, stream=True, out=dst)
                 c.H, c.W = 2 * c.H, 2 * c.W
             elif isinstance(layer, nn.Conv2d):  # stem
                 wp, b = c.w["stem"]
+                self._site(c, "split")
                 h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W, stream=True, out=dst)
             else:
                 raise TypeError(type(layer))
@@ -636,6 +652,7 @@ class UNetModel(packing.PackedWeights, nn.Module):
         c = _Ctx()
         c.ops, c.fp, c.w = self.ops, self.fp, packed
         c.B, c.T, c.F, c.H, c.W = b, t, b * t, hh, ww
+        c.H0, c.level0 = hh, 0  # (pyramid level of a norm site = level0 + log2(H0 / H): UNetModel._site)
         ops = c.ops
         T_total = t if c.fp is None else c.fp.total_frames
         ctx = context.to(device=ops.device, dtype=ops.dtype)
@@ -715,6 +732,7 @@ class UNetModel(packing.PackedWeights, nn.Module):
         h = self._gn(c, h, c.w["out_gn"], 1e-5, True, True)
         y = ops.conv3x3(h, c.w["out_conv"][0], c.w["out_conv"][1], c.F, c.H, c.W, stream=True)
         y = ops.unpack_output(y, c.F, hh * ww)  # [C, (clip, frame), pixel]
+        ops.site = None  # (calls outside the U-Net - first stage, Resampler - belong to no site)
         if b == 1:
             return y.reshape(1, self.out_channels, t, hh, ww)
         return y.reshape(self.out_channels, b, t, hh, ww).permute(1, 0, 2, 3, 4).contiguous()
