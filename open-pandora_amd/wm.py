@@ -192,7 +192,11 @@ class DiffusionRunner:
         (3, 4, H, W).  videos: (1, n_samples, 3, 16, H, W)."""
         x = videos[0, 0][:, -4:].detach().float().clamp(-1.0, 1.0)
         x8 = ((x + 1.0) / 2.0).mul(255.0).to(torch.uint8)
-        return (x8.float() / 255.0 - 0.5) / 0.5
+        # the way back to [-1, 1] is the reference's HOST arithmetic (ToTensor: / 255, Normalize: (t - 0.5) / 0.5, on the CPU):
+        # a 256-entry table computed there - the device's f32 division differs from it in the last bit for some of the 256
+        # values, which the bf16 conditioning frames then carry into the next round
+        lut = ((torch.arange(256, dtype=torch.float32) / 255.0) - 0.5) / 0.5
+        return lut.to(x8.device)[x8.long()]
 
     @torch.no_grad()
     def generate_multiround(self, conditionings, diffusion_pixel_values, diffusion_cond_image, **generate_kwargs):
