@@ -219,8 +219,8 @@ def test_oracle_72x128_fixture_matches_the_real_reference():
     """Two committed digests of the same full-width forward at 16x72x128: one from the oracle (chunked attention),
     one from the REAL reference (eager attention called per frame, oracle/make_golden.py --full-72x128)."""
     a, b = load("unet_full_72x128.npz"), load("unet_full_72x128_oracle.npz")
-    assert int(a["cond/stride"]) == int(b["cond/stride"])
     key = "cond/full" if "cond/full" in a and "cond/full" in b else "cond/slice"  # format 2 commits the latent whole
+    assert key == "cond/full" or int(a["cond/stride"]) == int(b["cond/stride"])
     assert rel(b[key], a[key]) < 2e-5
     for k in ("std", "mean", "absmax") + (("col_rms", "row_rms") if "cond/col_rms" in a and "cond/col_rms" in b else ()):
         assert np.allclose(a[f"cond/{k}"], b[f"cond/{k}"], rtol=2e-5, atol=2e-5 * float(a["cond/std"]))
