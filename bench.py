@@ -311,7 +311,7 @@ def committed_traffic(res, fam="gemm"):
     """HBM-side bytes per launch of a kernel family from the committed PMC summary (separate rocprofv3 --pmc passes over
     one eager forward, gfx950 FETCH_SIZE correction applied there: tools/pmc_traffic.py) - only when it was taken with
     the library sources of THIS run; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r04", "pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r05", "pmc_traffic.json")
     try:
         from open_pandora_amd import build as _b
         with open(path) as f:

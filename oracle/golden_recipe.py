@@ -140,8 +140,14 @@ def compare_digest(t, g, key, tol):
             e = _rel(got, g[f"{key}/{name}"])
             assert e <= tol, f"{key}/{name}: {e:.2e} > {tol:.1e}"
         for name, got in (("col_mean", cols.mean(0)), ("row_mean", rows.mean((0, 2)))):
-            e = float((got - torch.as_tensor(g[f"{key}/{name}"])).abs().max())
-            assert e <= tol * gstd, f"{key}/{name}: {e:.2e} > {tol:.1e} x std"
+            # a profile of means: L2 against the larger of its own norm and the noise floor std sqrt(n), and no single entry
+            # off by more than 3 tol std (a 16-bit output's rounding is correlated down a column whose entries share a binade:
+            # up to half an ulp of the column mean survives the average - measured 8e-3 std on the bf16 Resampler output)
+            ref = torch.as_tensor(g[f"{key}/{name}"])
+            e2 = float((got - ref).norm() / max(float(ref.norm()), gstd * ref.numel() ** 0.5))
+            assert e2 <= tol, f"{key}/{name}: {e2:.2e} > {tol:.1e}"
+            e = float((got - ref).abs().max())
+            assert e <= 3 * tol * gstd, f"{key}/{name}: {e:.2e} > 3 x {tol:.1e} x std"
     if f"{key}/full" in g:
         err = _rel(y, g[f"{key}/full"])
     else:

@@ -1,15 +1,15 @@
 #!/bin/bash
-# Round-4 measurement artefacts on the GPU box -> $OUT_ROOT/r04 (copy what is to be judged into profiles/r04 afterwards).
-# usage: tools/collect_profiles_r04.sh [a|b|c|all]   a = bench + kernel stats + per-forward tables; b = SQ counters of the
+# Round-5 measurement artefacts on the GPU box -> $OUT_ROOT/r05 (copy what is to be judged into profiles/r05 afterwards).
+# usage: tools/collect_profiles_r05.sh [a|b|c|all]   a = bench + kernel stats + per-forward tables; b = SQ counters of the
 # attention shapes; c = HBM-side traffic per launch (FETCH_SIZE / WRITE_SIZE passes of their own) -> pmc_traffic.json
 set -u
-PART=${1:-all}; O=${OUT_ROOT:-gpurun_out}/r04; mkdir -p $O
+PART=${1:-all}; O=${OUT_ROOT:-gpurun_out}/r05; mkdir -p $O
 export TMPDIR=/tmp
 PMC_SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
 INC="--kernel-include-regex pm"
 if [ $PART = a ] || [ $PART = all ]; then
 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_trace -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-baseline off --emulate-shard off > $O/bench_under_rocprof.json 2>/dev/null
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_trace -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-baseline off --emulate-shard off --parity-mode off > $O/bench_under_rocprof.json 2>/dev/null
 cp $O/bench_trace/*/*kernel_stats.csv $O/bench_kernel_stats.csv; rm -rf $O/bench_trace
 for res in 320x512 576x1024; do
   for n in 2 6; do
@@ -18,9 +18,8 @@ for res in 320x512 576x1024; do
   python3 tools/diff_stats.py $O/fwd_${res}_2/*/*kernel_stats.csv 2 $O/fwd_${res}_6/*/*kernel_stats.csv 6 > $O/forward_kernel_breakdown_$res.txt
   rm -rf $O/fwd_${res}_2 $O/fwd_${res}_6
 done
-timeout 600 python3 bench.py --steps 10 --warmup 3 --parity --dtype f16 --cpu-baseline off --emulate-shard off > $O/bench_parity_f16.json 2> $O/bench_parity_f16.err
-timeout 600 python3 bench.py --steps 10 --warmup 3 --dtype f16 --cpu-baseline off --emulate-shard off > $O/bench_f16.json 2> $O/bench_f16.err
-timeout 900 python3 bench.py --steps 10 --warmup 3 --cpu-baseline off --emulate-shard off --fp8-attention --multiround 5 > $O/bench_fp8_multiround.json 2>/dev/null
+timeout 600 python3 bench.py --steps 10 --warmup 3 --dtype f16 --cpu-baseline off --emulate-shard off --parity-mode off > $O/bench_f16.json 2> $O/bench_f16.err
+timeout 900 python3 bench.py --steps 10 --warmup 3 --cpu-baseline off --emulate-shard off --parity-mode off --fp8-attention --multiround 5 > $O/bench_fp8_multiround.json 2>/dev/null
 fi
 if [ $PART = b ] || [ $PART = all ]; then
 timeout 600 rocprofv3 --kernel-trace --pmc $PMC_SQ $INC --output-format csv -d $O/pmc_attn -- python3 tools/attn_pmc.py > /dev/null 2>&1
