@@ -103,6 +103,8 @@ def _rccl_worker(rank, port, out, kv_gather, T=16):
 @pytest.mark.parametrize("kv_gather,T", [(False, 16), (True, 16), (False, 2), (True, 2)],
                          ids=["reshard", "kv_gather", "reshard_2_frames_per_rank", "kv_gather_2_frames_per_rank"])
 def test_segmented_graph_replay_of_frame_sharded_forward(tmp_path, kv_gather, T):
+    if os.environ.get("PANDORA_HIPGRAPH", "1") == "0":
+        pytest.skip("PANDORA_HIPGRAPH=0 (the eager fallback switch): there is no graph replay to test")
     out = str(tmp_path / "seg.pt")
     mp.spawn(_rccl_worker, args=(_free_port(), out, kv_gather, T), nprocs=1, join=True)
     got = torch.load(out)

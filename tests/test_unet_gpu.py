@@ -147,7 +147,8 @@ def test_batched_clips_forward_and_sampler(hip_ops_factory, dtype, monkeypatch):
                       unconditional_guidance_scale=cfg, unconditional_conditioning=dev(uc), eta=eta,
                       fs=torch.tensor([15]).cuda(), timestep_spacing="uniform_trailing", x_T=ins["x_T"].cuda())
     graphs = list(smp._graphs.values())
-    assert len(graphs) == 1 and graphs[0].batched
+    # (PANDORA_HIPGRAPH=0, the eager fallback switch: the same batched forward, issued eagerly - no graph to look at)
+    assert (len(graphs) == 1 and graphs[0].batched) if smp.use_graph else not graphs
     err = rel(y.cpu(), g)
     print(f"\n[parity] ddim_small S={S} cfg={cfg} {dtype}, CFG pair batched into one forward: rel err {err:.2e}")
     assert err <= TRAJ_TOL_REDUCED[dtype]
@@ -174,7 +175,8 @@ def test_ddim_multicond_trajectory(hip_ops_factory, dtype, S, eta, cfg, cfg_img,
                        noise_fn=lambda i, shape: ns[i])[:, 0]
     err = rel(y.cpu(), g)
     graphs = list(smp._graphs.values())
-    assert len(graphs) == 1 and len(graphs[0].e_x) == 1  # ONE graph holds all three forwards of a step
+    # ONE graph holds all three forwards of a step (none under the eager fallback switch PANDORA_HIPGRAPH=0)
+    assert (len(graphs) == 1 and len(graphs[0].e_x) == 1) if smp.use_graph else not graphs
     print(f"\n[parity] ddim multi-condition S={S} eta={eta} cfg={cfg} cfg_img={cfg_img} gr={gres} {dtype}: rel err {err:.2e}")
     # three forwards enter with weights (1 - cfg_img), (cfg_img - cfg), cfg; the second case runs 20 steps at scale 7.5 (the
     # two-way bound assumes scale 4): 1.5 x the reduced-width trajectory tolerance.  Measured 2.5e-3 / 4.3e-3 (f16),
