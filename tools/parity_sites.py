@@ -14,12 +14,31 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-from oracle import golden_recipe as gr  # noqa: E402  (measurement tool: the fixture comparison helper)
 from open_pandora_amd import factory, synth  # noqa: E402
 from open_pandora_amd.autoencoder import AutoencoderKL  # noqa: E402
 from open_pandora_amd.ddim import DDIMSampler  # noqa: E402
 from open_pandora_amd.ops_hip import HipOps  # noqa: E402
+
+WEIGHT_SEED, INPUT_SEED = 20230211, 123  # (the fixtures' recipe: oracle/golden_recipe.py - nothing under oracle/ is imported here)
+
+
+def rel_to_fixture(t, g, key):
+    """relative L2 error against a fixture record: the whole tensor where the record holds it, else its prime-stride slice"""
+    y = t.detach().float().cpu().reshape(-1)
+    if f"{key}/full" in g:
+        ref = torch.from_numpy(g[f"{key}/full"]).reshape(-1)
+    else:
+        ref = torch.from_numpy(g[f"{key}/slice"])
+        y = y[::int(g[f"{key}/stride"])][:ref.numel()]
+    return float((y.double() - ref.double()).norm() / ref.double().norm())
+
+
+def sampler_inputs(h, w):
+    ins = synth.synth_inputs(h, w, 16, seed=INPUT_SEED)
+    cond = {"c_crossattn": [ins["c_crossattn"]], "c_concat": [ins["c_concat"]]}
+    uc = {"c_crossattn": [ins["uc_crossattn"]], "c_concat": [ins["c_concat"]]}
+    return ins, cond, uc
+
 
 KINDS = ["gn3", "gnt", "gnp", "lns1", "lns2", "lns3", "lnt1", "lnt2", "lnt3", "split"]
 ALL = [(k, lv) for k in KINDS for lv in range(4)]
@@ -29,8 +48,8 @@ def measure(res, sites, g, S=10, time_steps=6):
     h, w = factory.RESOLUTIONS[res]["image_size"]
     parity = True if sites == "all" else (False if not sites else sites)
     ops = HipOps(torch.float16, "cuda:0", parity=parity)
-    pm = factory.build_diffusion(res, ops, seed=gr.WEIGHT_SEED)
-    ins, cond, uc = gr.sampler_inputs(h, w)
+    pm = factory.build_diffusion(res, ops, seed=WEIGHT_SEED)
+    ins, cond, uc = sampler_inputs(h, w)
     dev = lambda c: {k: [t.cuda() for t in v] for k, v in c.items()}
     smp = DDIMSampler(pm)
     kw = dict(batch_size=1, shape=(4, 16, h, w), conditioning=dev(cond), verbose=False, unconditional_guidance_scale=4.0,
@@ -44,10 +63,9 @@ def measure(res, sites, g, S=10, time_steps=6):
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / time_steps
     ae = AutoencoderKL()
-    ae.load_state_dict(synth.synth_state_dict(ae, seed=gr.WEIGHT_SEED))
+    ae.load_state_dict(synth.synth_state_dict(ae, seed=WEIGHT_SEED))
     frames = ae.bind(HipOps(torch.float16, "cuda:0", parity=True)).decode_first_stage(z)
-    e_z = gr.compare_digest(z, g, "latent", 1.0)[0]
-    e_f = gr.compare_digest(frames, g, "frames", 1.0)[0]
+    e_z, e_f = rel_to_fixture(z, g, "latent"), rel_to_fixture(frames, g, "frames")
     smp.close()
     del pm, ae, smp
     torch.cuda.empty_cache()
