@@ -73,6 +73,8 @@ class HipOps:
             if parity != "selective":
                 raise ValueError(f"parity={parity!r}: True, False, 'selective' or a collection of (kind, level) sites")
             parity = SELECTIVE_PARITY_SITES
+        if isinstance(parity, int) and not isinstance(parity, bool):
+            parity = bool(parity)
         if not isinstance(parity, bool) and parity is not None:
             self.parity_sites = frozenset((str(k), int(lv)) for k, lv in parity)
             parity = True

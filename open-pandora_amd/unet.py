@@ -195,7 +195,7 @@ class TimestepEmbedSequential(nn.Sequential):
 class _Ctx:
     """Per-forward execution state."""
     __slots__ = ("ops", "fp", "F", "H", "W", "emb_bias", "ctx_text", "ctx_img", "w", "stats", "kv_text", "kv_img",
-                 "img_shared", "B", "T", "H0", "level0")  # B clips of T frames each batched along the rows: F = B * T (B = 1: the reference's call)
+                 "img_shared", "B", "T", "level")  # B clips of T frames each batched along the rows: F = B * T (B = 1: the reference's call)
 
 
 class UNetModel(packing.PackedWeights, nn.Module):
@@ -394,7 +394,7 @@ class UNetModel(packing.PackedWeights, nn.Module):
         site; others ignore the attribute.  Kinds: gn3 / gnt = GroupNorm + SiLU in front of a 3x3 / temporal conv, gnp = the
         transformers' GroupNorm in front of proj_in, lns1 / lns2 / lns3 (lnt*) = LayerNorm in front of the spatial (temporal)
         block's attn1 projection / attn2 projection / GEGLU, split = the f32 stream into a Downsample / Upsample / stem conv."""
-        c.ops.site = (kind, c.level0 + (c.H0 // max(1, c.H)).bit_length() - 1)
+        c.ops.site = (kind, c.level)
 
     def _gn(self, c, x, gb, eps, silu, per_frame, totals=None):
         """`totals`: {sum, sumsq} already produced by the epilogue of the op that wrote x."""
@@ -583,7 +583,7 @@ class UNetModel(packing.PackedWeights, nn.Module):
                 wp, b = c.w[self._names[layer]]
                 self._site(c, "split")
                 h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W, stride=2, stream=True, out=dst)
-                c.H, c.W = (c.H + 1) // 2, (c.W + 1) // 2
+                c.H, c.W, c.level = (c.H + 1) // 2, (c.W + 1) // 2, c.level + 1
             elif isinstance(layer, Upsample):
                 wp, b = c.w[self._names[layer]]
                 # (r03 kept the gathered form for frame shards because tests/test_segmented_gpu.py aborted with the written-out
@@ -591,7 +591,7 @@ class UNetModel(packing.PackedWeights, nn.Module):
                 # frame_parallel.FrameParallel._comm - and had nothing to do with this op: one form everywhere again)
                 self._site(c, "split")
                 h = c.ops.conv3x3(h, wp, b, c.F, c.H, c.W, upsample=True, stream=True, out=dst)
-                c.H, c.W = 2 * c.H, 2 * c.W
+                c.H, c.W, c.level = 2 * c.H, 2 * c.W, c.level - 1
             elif isinstance(layer, nn.Conv2d):  # stem
                 wp, b = c.w["stem"]
                 self._site(c, "split")
@@ -652,7 +652,7 @@ class UNetModel(packing.PackedWeights, nn.Module):
         c = _Ctx()
         c.ops, c.fp, c.w = self.ops, self.fp, packed
         c.B, c.T, c.F, c.H, c.W = b, t, b * t, hh, ww
-        c.H0, c.level0 = hh, 0  # (pyramid level of a norm site = level0 + log2(H0 / H): UNetModel._site)
+        c.level = 0  # (pyramid level of the norm sites, UNetModel._site: +1 behind every Downsample, -1 behind every Upsample)
         ops = c.ops
         T_total = t if c.fp is None else c.fp.total_frames
         ctx = context.to(device=ops.device, dtype=ops.dtype)

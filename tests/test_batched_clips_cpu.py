@@ -81,3 +81,25 @@ def test_batch_mode_falls_back_to_two_forwards_for_per_clip_kwargs_and_inference
     with torch.inference_mode():
         v = torch.ones(3)
     assert ddim._version_of(v) == 0 and ddim._version_of(torch.ones(3)) == 0
+
+
+def test_norm_sites_are_named_by_kind_and_pyramid_level():
+    """UNetModel._site (the handle of HipOps(parity="selective")): every GroupNorm / LayerNorm / stream
+    conversion call of a forward carries (kind, level) in `ops.site` - the level counted by the Down / Upsample modules passed,
+    not derived from the latent size - and the attribute is cleared when the forward returns (first stage / Resampler calls belong to no
+    site)."""
+    m = _model()
+    ops, seen = m.ops, set()
+    for name in ("groupnorm", "ln_gemm", "conv3x3"):
+        inner = getattr(ops, name)
+        setattr(ops, name, (lambda f, n: lambda *a, **k: (seen.add((n, ops.site)), f(*a, **k))[1])(inner, name))
+    ins = synth.synth_inputs(24, 8, 16, seed=gr.INPUT_SEED)  # 24 x 8 -> 12 x 4 -> 6 x 2 -> 3 x 1 (not a power of two)
+    x = torch.cat([ins["x_T"], ins["c_concat"]], 1)
+    m(x, torch.tensor([500]), context=ins["c_crossattn"], fs=torch.tensor([15]))
+    assert ops.site is None
+    gn = {s for n, s in seen if n == "groupnorm"}
+    assert gn == {(k, lv) for k in ("gn3", "gnt", "gnp") for lv in range(4)}
+    ln = {s for n, s in seen if n == "ln_gemm"}
+    assert ln == {(f"ln{b}{i}", lv) for b in "st" for i in (1, 2, 3) for lv in range(4)}
+    split = {s for n, s in seen if n == "conv3x3" and s is not None and s[0] == "split"}
+    assert split == {("split", 0), ("split", 1), ("split", 2), ("split", 3)}  # stem + Downsample 0-2 | Upsample from 3, 2, 1
