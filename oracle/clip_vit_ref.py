@@ -2,9 +2,14 @@
 FrozenOpenCLIPImageEmbedderV2 runs it (condition.py:300-382), functional over a state_dict with open_clip's key
 names under `model.visual.`.
 
-PARITY UNPINNED for this module: the arithmetic lives in the third-party `open_clip_torch` (pinned 2.22.0 in
-DynamiCrafter/requirements.txt:22; absent from this image and from /root/reference), so there is no reference
-output to pin against.  Restated from the published architecture - open_clip/transformer.py `VisionTransformer`
+PARITY of this module: the arithmetic lives in the third-party `open_clip_torch` (pinned 2.22.0 in
+DynamiCrafter/requirements.txt:22; absent from this image and from /root/reference): there is no open_clip output to pin
+against - "parity unpinned" against THAT package.  Since r05 the restatement is pinned against a third-party
+implementation of the same architecture that IS in the image: HF `transformers.CLIPVisionModel.last_hidden_state` (the
+class that loads the laion/CLIP-ViT-H-14-laion2B-s32B-b79K conversion of the checkpoint the reference pulls through
+open_clip) on seeded weights in open_clip's key layout, reduced and full ViT-H/14 size, 2e-5
+(tests/golden/clip_vision_hf.npz, oracle/make_golden.py --clip-hf, tests/test_clip_vision_cpu.py).  Restated from the
+published architecture - open_clip/transformer.py `VisionTransformer`
 (conv1 patchify without bias, class token + learned positions, ln_pre, pre-LN `ResidualAttentionBlock`s built on
 nn.MultiheadAttention and Linear-GELU-Linear) - and anchored on the reference's own call site: all tokens of the
 transformer output, no ln_post, no projection (condition.py:353-382); preprocessing = torchvision Resize((224, 224))

@@ -25,6 +25,21 @@ RESAMPLER_CASES = (("small", dict(dim=128, depth=2, dim_head=64, heads=2, num_qu
                                  output_dim=1024, ff_mult=4, video_length=16), (1, 257, 1280)))
 
 
+# image tower (clip_vision): seeded weights and images shared by oracle/make_golden.py --clip-hf and the tests
+CLIP_SEED = 7
+CLIP_SMALL = dict(image_size=56, patch_size=14, width=320, layers=3, heads=4, mlp_ratio=4.0, output_dim=64)  # head dim 80
+
+
+def clip_image(tag):
+    """(b, 3, H, W) in [-1, 1], NOT at the tower's input size: the preprocessing (resize + normalise) is part of the path."""
+    b, h, w = (2, 70, 90) if tag == "small" else (1, 320, 512)
+    return uniform_image(b, h, w, f"clip/{tag}")
+
+
+def uniform_image(b, h, w, name):
+    return synth.uniform_pm1(b * 3 * h * w, INPUT_SEED, name).reshape(b, 3, h, w)
+
+
 def module_input(name, *shape):
     return (synth.uniform_pm1(int(np.prod(shape)), INPUT_SEED, name) * 3 ** 0.5).reshape(*shape)
 

@@ -145,6 +145,58 @@ def gen_learnable():
     save("unet_small_learnable.npz", **out)
 
 
+def gen_clip_hf():
+    """The image tower against a THIRD-PARTY implementation that is present in this image: HF `transformers.CLIPVisionModel`
+    (the class that loads the laion/CLIP-ViT-H-14-laion2B-s32B-b79K conversion of the very checkpoint the reference pulls
+    through open_clip, condition.py:306-308).  open_clip_torch itself (pinned 2.22.0, DynamiCrafter/requirements.txt:22) stays
+    absent, so this pins the architecture's arithmetic - patch conv, class + position embeddings, pre-LN blocks, fused-qkv
+    attention at head dim 80, GELU MLP, all tokens of the LAST block without post-LN / projection = HF's `last_hidden_state` =
+    the reference's call site (condition.py:353-382) - not open_clip's code.  Seeded weights in open_clip's key layout
+    (`model.visual.*`), mapped key by key onto the HF module; input = the preprocessed 224 x 224 pixels."""
+    import transformers
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    from oracle import clip_vit_ref
+    from open_pandora_amd.clip_vision import VIT_H_14, FrozenOpenCLIPImageEmbedderV2
+    out = {"source": np.array(f"transformers {transformers.__version__} CLIPVisionModel.last_hidden_state (f32, CPU)")}
+    for tag, cfg in (("small", gr.CLIP_SMALL), ("vit_h_14", dict(VIT_H_14))):
+        with torch.device("meta"):
+            prod = FrozenOpenCLIPImageEmbedderV2(vision_cfg=cfg)
+        sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in prod.state_dict().items()}, seed=gr.CLIP_SEED)
+        C, L, H = cfg["width"], cfg["layers"], cfg["heads"]
+        hf = CLIPVisionModel(CLIPVisionConfig(hidden_size=C, intermediate_size=int(C * cfg["mlp_ratio"]), num_hidden_layers=L,
+                                              num_attention_heads=H, image_size=cfg["image_size"], patch_size=cfg["patch_size"],
+                                              hidden_act="gelu", layer_norm_eps=1e-5, attention_dropout=0.0)).eval()
+        v = "model.visual."
+        m = {"vision_model.embeddings.class_embedding": sd[v + "class_embedding"],
+             "vision_model.embeddings.patch_embedding.weight": sd[v + "conv1.weight"],
+             "vision_model.embeddings.position_embedding.weight": sd[v + "positional_embedding"],
+             "vision_model.pre_layrnorm.weight": sd[v + "ln_pre.weight"], "vision_model.pre_layrnorm.bias": sd[v + "ln_pre.bias"],
+             "vision_model.post_layernorm.weight": sd[v + "ln_post.weight"], "vision_model.post_layernorm.bias": sd[v + "ln_post.bias"]}
+        for i in range(L):
+            a, b = f"{v}transformer.resblocks.{i}.", f"vision_model.encoder.layers.{i}."
+            w, bias = sd[a + "attn.in_proj_weight"], sd[a + "attn.in_proj_bias"]
+            for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
+                m[f"{b}self_attn.{n}.weight"], m[f"{b}self_attn.{n}.bias"] = w[j * C:(j + 1) * C], bias[j * C:(j + 1) * C]
+            for src, dst in (("attn.out_proj", "self_attn.out_proj"), ("ln_1", "layer_norm1"), ("ln_2", "layer_norm2"),
+                             ("mlp.c_fc", "mlp.fc1"), ("mlp.c_proj", "mlp.fc2")):
+                m[f"{b}{dst}.weight"], m[f"{b}{dst}.bias"] = sd[a + src + ".weight"], sd[a + src + ".bias"]
+        have = {k for k in hf.state_dict() if not k.endswith("position_ids")}
+        if not any(k.startswith("vision_model.") for k in have):  # (transformers >= 5 dropped the wrapper level)
+            m = {k[len("vision_model."):]: val for k, val in m.items()}
+        assert set(m) == have, sorted(set(m) ^ have)[:6]
+        missing, unexpected = hf.load_state_dict(m, strict=False)
+        assert not unexpected and all(k.endswith("position_ids") for k in missing), (missing, unexpected)
+        img = gr.clip_image(tag)
+        px = clip_vit_ref.preprocess(img, cfg["image_size"])
+        t0 = time.time()
+        with torch.no_grad():
+            y = hf(pixel_values=px).last_hidden_state
+        print(f"HF CLIPVisionModel {tag}: {time.time() - t0:.1f}s out {tuple(y.shape)} std {y.std():.4f}")
+        for k, val in digest(y).items():
+            out[f"{tag}/{k}"] = val
+    save("clip_vision_hf.npz", **out)
+
+
 def gen_unet_ctx():
     """The `else` branch of UNetModel.forward's context handling (openaimodel3d.py:565-566): a context that is not
     77 + 16 t tokens long is repeated for every frame; CrossAttention still splits it at token 77."""
@@ -480,6 +532,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full-72x128", action="store_true")
     ap.add_argument("--ctx", action="store_true")
+    ap.add_argument("--clip-hf", action="store_true", help="image tower fixtures from transformers' CLIPVisionModel")
     ap.add_argument("--learnable", action="store_true", help="image_cross_attention_scale_learnable fixtures (256 yaml)")
     ap.add_argument("--traj-72x128", type=int, default=0)
     ap.add_argument("--full", action="store_true")
@@ -505,6 +558,9 @@ if __name__ == "__main__":
         if a.frames_full:
             gen_frames_full([(int(c.split(":")[0]), float(c.split(":")[1])) for c in a.frames_full.split(",")],
                             forwards=a.with_forwards)
+        sys.exit(0)
+    if a.clip_hf:
+        gen_clip_hf()
         sys.exit(0)
     if a.learnable:
         assert rh.available()

@@ -48,3 +48,31 @@ def test_tower_graph_matches_oracle_and_torch_modules():
         x = x + blk.attn(y, y, y, need_weights=False)[0]
         x = x + blk.mlp(blk.ln_2(x))
     assert ((got - x.permute(1, 0, 2)).norm() / want.norm()).item() < 2e-5
+
+
+def test_oracle_and_product_against_the_hf_clip_vision_model_fixture():
+    """r05: the tower pinned to a third-party implementation that IS in the image - HF transformers' CLIPVisionModel, the
+    class that loads the laion ViT-H-14 conversion of the checkpoint the reference pulls through open_clip
+    (`last_hidden_state` = all tokens of the last block, no post-LN, no projection = condition.py:353-382) - on seeded weights
+    in open_clip's key layout (oracle/make_golden.py --clip-hf).  The oracle restatement at both sizes, the product graph on
+    the oracle's op table at the reduced size (the full-size product runs on the GPU)."""
+    import os
+
+    import numpy as np
+
+    from oracle import golden_recipe as gr
+    from open_pandora_amd.clip_vision import VIT_H_14
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "clip_vision_hf.npz"))
+    assert "CLIPVisionModel" in str(g["source"])
+    for tag, cfg in (("small", gr.CLIP_SMALL), ("vit_h_14", dict(VIT_H_14))):
+        with torch.device("meta"):
+            shapes = {k: tuple(v.shape) for k, v in FrozenOpenCLIPImageEmbedderV2(vision_cfg=cfg).state_dict().items()}
+        sd = synth.synth_state_dict(shapes, seed=gr.CLIP_SEED)
+        img = gr.clip_image(tag)
+        y = clip_vit_ref.vision_tower_forward(sd, img, cfg["heads"], cfg["image_size"])
+        err = gr.compare_digest(y, g, tag, 2e-5)[0]
+        assert err < 2e-5, (tag, err)
+        if tag == "small":
+            m = FrozenOpenCLIPImageEmbedderV2(vision_cfg=cfg)
+            m.load_state_dict(sd)
+            assert gr.compare_digest(m.bind(TorchOps())(img), g, tag, 2e-5)[0] < 2e-5

@@ -1,5 +1,5 @@
 """GPU: the OpenCLIP ViT image tower on the HIP kernels (pm_gemm, pm_layernorm, pm_attention_generic with head dim 80)
-against the oracle restatement (parity unpinned for this module: oracle/clip_vit_ref.py says why), reduced and
+against the oracle restatement and against the fixture of HF transformers' CLIPVisionModel (oracle/clip_vit_ref.py: what is pinned and what is not), reduced and
 full ViT-H/14 size, and chained with the Resampler through wm.ImageContext."""
 import pytest
 import torch
@@ -54,3 +54,24 @@ def test_tower_vit_h_14_and_image_context(hip_ops_factory, dtype):
     assert tokens.shape == (1, 256, 1024) and torch.isfinite(tokens).all()
     u1, u2 = ctx.uncond(img.cuda()), ctx.uncond(img.cuda())
     assert u1 is u2 and u1.shape == (1, 256, 1024)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_tower_against_the_hf_clip_vision_model_fixture(hip_ops_factory, dtype):
+    """The HIP tower at both sizes against the fixture of HF transformers' CLIPVisionModel (tests/golden/clip_vision_hf.npz,
+    oracle/make_golden.py --clip-hf): a third-party implementation of the architecture, not the builder's restatement."""
+    import os
+
+    import numpy as np
+
+    from oracle import golden_recipe as gr
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "clip_vision_hf.npz"))
+    for tag, cfg, tol in (("small", gr.CLIP_SMALL, FWD_TOL_REDUCED[dtype]), ("vit_h_14", dict(VIT_H_14), 2 * FWD_TOL[dtype])):
+        with torch.device("meta"):
+            m = FrozenOpenCLIPImageEmbedderV2(vision_cfg=cfg)
+        m.load_state_dict({k: synth.synth_tensor(k, tuple(v.shape), gr.CLIP_SEED, "cuda") for k, v in m.state_dict().items()},
+                          assign=True)
+        got = m.bind(hip_ops_factory(dtype))(gr.clip_image(tag).cuda())
+        err = gr.compare_digest(got, g, tag, tol)[0]
+        print(f"\n[parity] clip tower {tag} {dtype} vs HF CLIPVisionModel: rel err {err:.2e}")
+        assert err <= tol
