@@ -376,7 +376,7 @@ class DDIMSampler:
         self._sqrt_1mac = m.sqrt_one_minus_alphas_cumprod.detach().to(torch.float32).cpu().numpy()
 
     def step_scalars(self, index, step):
-        """f32 scalars of p_sample_ddim (ddim.py:252-288) for the v-parameterisation."""
+        """f32 scalars of p_sample_ddim (ddim.py:252-288) for the fused update kernel: v- and eps-parameterisation."""
         f32 = np.float32
         a_prev = f32(self.ddim_alphas_prev[index])
         sigma = f32(self.ddim_sigmas[index].item())
@@ -385,6 +385,19 @@ class DDIMSampler:
         rescale = f32(1.0)
         if self.model.use_dynamic_rescale:
             rescale = f32(self.ddim_scale_arr_prev[index].item()) / f32(self.ddim_scale_arr[index].item())
+        if getattr(self.model, "parameterization", "v") == "eps":
+            # eps-prediction (the 256 yaml's class default; ddim.py:245-246,265-266): e_t = model output,
+            #     pred_x0 = (x - s1 e_t) / sa * r,    x_prev = P pred_x0 + D e_t + noise,    sa = sqrt(a_t), s1 = sqrt(1 - a_t).
+            # The fused kernel computes  eps_k = A v + B x,  x0_k = (A x - B v) R,  x_prev = P' x0_k + D' eps_k  (pm_ddim_update).
+            # With A = 1, B = s1, R = r / sa its x0_k IS pred_x0, and eps_k = v + s1 x = (1 + s1^2) v + (s1 sa / r) x0_k, so
+            # D' = D / (1 + s1^2), P' = P - D' s1 sa / r give the reference's update exactly (f64 here, f32 in the kernel):
+            # no second kernel flavour for a parameterisation Open-Pandora itself does not ship.
+            sa = float(np.sqrt(f32(self.ddim_alphas[index].item()), dtype=f32))
+            s1 = float(f32(self.ddim_sqrt_one_minus_alphas[index].item()))
+            P, D, r = float(np.sqrt(a_prev, dtype=f32)), float(dir_coef), float(rescale)
+            Dk = D / (1.0 + s1 * s1)
+            return dict(sqrt_ac=1.0, sqrt_1mac=s1, rescale=r / sa, sqrt_a_prev=P - Dk * s1 * sa / r, dir_coef=Dk,
+                        sigma=float(sigma))
         return dict(sqrt_ac=float(self._sqrt_ac[step]), sqrt_1mac=float(self._sqrt_1mac[step]),
                     rescale=float(rescale), sqrt_a_prev=float(np.sqrt(a_prev, dtype=f32)),
                     dir_coef=float(dir_coef), sigma=float(sigma))

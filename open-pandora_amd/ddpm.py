@@ -58,8 +58,8 @@ class LatentVisualDiffusion(nn.Module):
                  use_dynamic_rescale=True, base_scale=0.7, turning_step=400, scale_factor=0.18215,
                  channels=4, image_size=(40, 64), **unused):
         super().__init__()
-        if parameterization != "v":
-            raise NotImplementedError("the shipped Open-Pandora configs use v-prediction")
+        if parameterization not in ("v", "eps"):  # ("x0": no shipped config; eps = the 256 yaml's class default)
+            raise NotImplementedError(f"parameterization={parameterization!r}: the shipped configs use v- or eps-prediction")
         self.parameterization = parameterization
         self.rescale_betas_zero_snr = rescale_betas_zero_snr
         self.channels = channels

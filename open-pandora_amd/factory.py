@@ -39,6 +39,9 @@ def build_diffusion(resolution="320x512", ops=None, seed=20230211, unet_override
     if yaml_path is not None:
         y = params_from_yaml(yaml_path)
         up = dict(y["unet_config"]["params"])
+        # what a yaml does not set takes the reference CLASS defaults (ddpm3d.py:54-76: eps-prediction, no zero-terminal-SNR
+        # rescale, no dynamic rescale) - the 256 yaml sets none of the three - not the 512 yaml's values
+        shell.update(parameterization="eps", rescale_betas_zero_snr=False, use_dynamic_rescale=False)
         for k in list(shell) + ["base_scale", "image_size"]:
             if k in y:
                 (r if k in ("base_scale", "image_size") else shell)[k] = y[k]

@@ -15,19 +15,24 @@ import numpy as np
 import torch
 
 
-def schedule_tables(timesteps=1000, linear_start=0.00085, linear_end=0.012, base_scale=0.7, turning_step=400):
+def schedule_tables(timesteps=1000, linear_start=0.00085, linear_end=0.012, base_scale=0.7, turning_step=400,
+                    zero_snr=True, dynamic_rescale=True):
+    """zero_snr / dynamic_rescale False: the class defaults of ddpm3d.py:54-76 that the 256 yaml runs with (no
+    rescale_zero_terminal_snr, scale array of ones = `use_dynamic_rescale: False`)."""
     betas = (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, timesteps, dtype=torch.float64) ** 2).numpy()
-    # zero-terminal-SNR rescale
-    s = np.sqrt(np.cumprod(1.0 - betas, axis=0))
-    s0, sT = s[0].copy(), s[-1].copy()
-    s -= sT
-    s *= s0 / (s0 - sT)
-    bar = s ** 2
-    alphas = np.concatenate([bar[0:1], bar[1:] / bar[:-1]])
-    betas = 1 - alphas
+    if zero_snr:  # zero-terminal-SNR rescale
+        s = np.sqrt(np.cumprod(1.0 - betas, axis=0))
+        s0, sT = s[0].copy(), s[-1].copy()
+        s -= sT
+        s *= s0 / (s0 - sT)
+        bar = s ** 2
+        alphas = np.concatenate([bar[0:1], bar[1:] / bar[:-1]])
+        betas = 1 - alphas
     ac = np.cumprod(1.0 - betas, axis=0)
     bf = lambda a: torch.tensor(a, dtype=torch.bfloat16)
     scale_arr = np.concatenate((np.linspace(1.0, base_scale, turning_step), np.full(timesteps, base_scale)))
+    if not dynamic_rescale:
+        scale_arr = np.ones_like(scale_arr)
     return {"alphas_cumprod": bf(ac), "sqrt_alphas_cumprod": bf(np.sqrt(ac)),
             "sqrt_one_minus_alphas_cumprod": bf(np.sqrt(1.0 - ac)), "scale_arr": bf(scale_arr)}
 
@@ -54,7 +59,8 @@ def ddim_tables(tables, S, eta, spacing):
 
 @torch.no_grad()
 def ddim_sample(apply_model, tables, x_T, cond, uncond, S, eta, cfg_scale, spacing="uniform_trailing",
-                noises=None, fs=None, keep_pred_x0=False, guidance_rescale=0.0, uncond_img=None, cfg_img=None):
+                noises=None, fs=None, keep_pred_x0=False, guidance_rescale=0.0, uncond_img=None, cfg_img=None,
+                parameterization="v"):
     """apply_model(x, t, cond, fs) -> v prediction.  noises: list of S tensors (one per loop
     iteration, same shape as x_T) consumed when eta > 0.  Returns (x_0 sample, [pred_x0 per step])."""
     d = ddim_tables(tables, S, eta, spacing)
@@ -85,10 +91,15 @@ def ddim_sample(apply_model, tables, x_T, cond, uncond, S, eta, cfg_scale, spaci
                 dims = list(range(1, v.dim()))
                 resc = v * (e_c.std(dim=dims, keepdim=True) / v.std(dim=dims, keepdim=True))
                 v = guidance_rescale * resc + (1 - guidance_rescale) * v
-        sa = tables["sqrt_alphas_cumprod"][t].reshape(size)         # bf16 scalars, promoted by x
-        sm = tables["sqrt_one_minus_alphas_cumprod"][t].reshape(size)
-        e_t = sa * v + sm * x
-        pred_x0 = sa * x - sm * v
+        if parameterization == "v":
+            sa = tables["sqrt_alphas_cumprod"][t].reshape(size)         # bf16 scalars, promoted by x
+            sm = tables["sqrt_one_minus_alphas_cumprod"][t].reshape(size)
+            e_t = sa * v + sm * x
+            pred_x0 = sa * x - sm * v
+        else:  # eps (ddim.py:245-246,265-266): the model output IS e_t; x0 from the DDIM tables of this step
+            e_t = v
+            a_t = full(d["alphas"][index])
+            pred_x0 = (x - full(torch.sqrt(1.0 - d["alphas"])[index]) * e_t) / a_t.sqrt()
         a_prev, sigma_t = full(d["alphas_prev"][index]), full(d["sigmas"][index])
         pred_x0 = pred_x0 * (full(d["scale_prev"][index]) / full(d["scale"][index]))
         dir_xt = (1.0 - a_prev - sigma_t ** 2).sqrt() * e_t

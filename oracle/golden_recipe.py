@@ -12,6 +12,11 @@ UNET_SMALL_CASES = (("mc64_8x8_t500", 64, 8, 8, 500, 15), ("mc64_8x16_t999", 64,
 UNET_CTX_CASES = ((82, "ctx82_shared_image_tokens"), (77, "ctx77_text_only"))
 # UNetModel params of configs/inference_256_v1.0.yaml:19-50 that differ from the 512 / 1024 yaml
 UNET_256_OVERRIDES = dict(image_cross_attention_scale_learnable=True, default_fs=3)
+# the 256 yaml's diffusion shell (configs/inference_256_v1.0.yaml:1-17): eps-prediction, no zero-terminal-SNR rescale, no
+# dynamic rescale - the class defaults of ddpm3d.py:54-76 - cases (S, eta, cfg)
+SHELL_256 = dict(parameterization=None, rescale_betas_zero_snr=None, use_dynamic_rescale=None, base_scale=None,
+                 fps_condition_type=None, perframe_ae=None, image_size=[32, 32])
+DDIM_EPS_CASES = ((5, 0.0, 4.0), (20, 1.0, 7.5))
 DDIM_SMALL_CASES = ((5, 0.0, 4.0), (10, 0.0, 4.0), (20, 1.0, 4.0), (10, 0.0, 1.0), (10, 1.0, 4.0))
 FRAMES_SMALL_CASES = ((5, 0.0), (50, 1.0))  # (S, eta): sampler -> decode_first_stage, cfg 4
 DDIM_RESCALE_CASES = ((5, 0.0, 4.0, 0.7), (20, 1.0, 4.0, 0.3))  # (S, eta, cfg, guidance_rescale)

@@ -145,6 +145,32 @@ def gen_learnable():
     save("unet_small_learnable.npz", **out)
 
 
+def gen_ddim_eps():
+    """The 256 model's sampler path: `parameterization == "eps"` (ddim.py:243-246,265-266: e_t = model output, pred_x0 =
+    (x - sqrt(1 - a) e_t) / sqrt(a)), schedule without zero-terminal-SNR rescale, no dynamic rescale - the REAL
+    LatentVisualDiffusion built with the 256 yaml's shell parameters and its unet_config at reduced width, the REAL DDIMSampler."""
+    import yaml
+    rh._install_shims()
+    import lvdm.models.samplers.ddim as refddim
+    with open(os.path.join(rh.REFERENCE_ROOT, "DynamiCrafter", "configs", "inference_256_v1.0.yaml")) as f:
+        kw = yaml.safe_load(f)["model"]["params"]["unet_config"]["params"]
+    m = rh.reference_diffusion(dict(kw, model_channels=64, use_checkpoint=False), shell=gr.SHELL_256)
+    assert m.parameterization == "eps" and not m.use_dynamic_rescale
+    m.model.diffusion_model.load_state_dict(synth.synth_state_dict(m.model.diffusion_model, seed=WEIGHT_SEED))
+    ins, cond, uc = _small_setup()
+    out = {"alphas_cumprod": m.alphas_cumprod.float().numpy()}
+    for S, eta, cfg in gr.DDIM_EPS_CASES:
+        noises = iter(gr.noises(ins["x_T"].shape, S))
+        refddim.noise_like = lambda shape, device, repeat=False: next(noises)
+        smp = rh.reference_sampler(m)
+        y, _ = smp.sample(S=S, batch_size=1, shape=(4, 16, 8, 8), conditioning=cond, verbose=False,
+                          unconditional_guidance_scale=cfg, unconditional_conditioning=uc, eta=eta, fs=torch.tensor([3]),
+                          timestep_spacing="uniform_trailing", x_T=ins["x_T"])
+        out[f"S{S}_eta{eta:g}_cfg{cfg:g}"] = y.numpy()
+        print(f"eps S={S} eta={eta} cfg={cfg}: std {y.std():.4f}")
+    save("ddim_small_eps.npz", **out)
+
+
 def gen_clip_hf():
     """The image tower against a THIRD-PARTY implementation that is present in this image: HF `transformers.CLIPVisionModel`
     (the class that loads the laion/CLIP-ViT-H-14-laion2B-s32B-b79K conversion of the very checkpoint the reference pulls
@@ -532,6 +558,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full-72x128", action="store_true")
     ap.add_argument("--ctx", action="store_true")
+    ap.add_argument("--eps", action="store_true", help="the 256 model's eps-parameterised sampler path (reduced width)")
     ap.add_argument("--clip-hf", action="store_true", help="image tower fixtures from transformers' CLIPVisionModel")
     ap.add_argument("--learnable", action="store_true", help="image_cross_attention_scale_learnable fixtures (256 yaml)")
     ap.add_argument("--traj-72x128", type=int, default=0)
@@ -558,6 +585,10 @@ if __name__ == "__main__":
         if a.frames_full:
             gen_frames_full([(int(c.split(":")[0]), float(c.split(":")[1])) for c in a.frames_full.split(",")],
                             forwards=a.with_forwards)
+        sys.exit(0)
+    if a.eps:
+        assert rh.available()
+        gen_ddim_eps()
         sys.exit(0)
     if a.clip_hf:
         gen_clip_hf()

@@ -64,8 +64,11 @@ class AttrDict(dict):
         return AttrDict(v) if isinstance(v, dict) else v
 
 
-def reference_diffusion(unet_overrides=None, base_scale=0.7, unet_target="lvdm.modules.networks.openaimodel3d.UNetModel"):
-    """LatentVisualDiffusion (ddpm3d.py:1036) with Identity condition stages and first stage."""
+def reference_diffusion(unet_overrides=None, base_scale=0.7, unet_target="lvdm.modules.networks.openaimodel3d.UNetModel",
+                        shell=None):
+    """LatentVisualDiffusion (ddpm3d.py:1036) with Identity condition stages and first stage.  `shell`: overrides of the
+    512 yaml's `model.params` (a value of None removes the key: the class default applies, as for the 256 yaml, which sets
+    neither `parameterization` nor `rescale_betas_zero_snr` nor `use_dynamic_rescale`)."""
     _install_shims()
     import torch
     from lvdm.models.ddpm3d import LatentVisualDiffusion
@@ -81,6 +84,11 @@ def reference_diffusion(unet_overrides=None, base_scale=0.7, unet_target="lvdm.m
         unet_config=AttrDict(target=unet_target, params=AttrDict(up)),
         first_stage_config=ident, cond_stage_config=ident, img_cond_stage_config=ident,
         image_proj_stage_config=ident)
+    for k, val in (shell or {}).items():
+        if val is None:
+            cfg.pop(k, None)
+        else:
+            cfg[k] = val
     model = LatentVisualDiffusion(**cfg).eval()
     return model
 

@@ -224,3 +224,35 @@ def test_oracle_72x128_fixture_matches_the_real_reference():
     assert rel(b[key], a[key]) < 2e-5
     for k in ("std", "mean", "absmax") + (("col_rms", "row_rms") if "cond/col_rms" in a and "cond/col_rms" in b else ()):
         assert np.allclose(a[f"cond/{k}"], b[f"cond/{k}"], rtol=2e-5, atol=2e-5 * float(a["cond/std"]))
+
+
+@pytest.mark.parametrize("S,eta,cfg", gr.DDIM_EPS_CASES)
+def test_ddim_eps_parameterisation_against_reference(S, eta, cfg):
+    """The 256 yaml's sampler path (eps-prediction, no zero-terminal-SNR rescale, no dynamic rescale; ddim.py:243-246,265-266)
+    against the REAL LatentVisualDiffusion + DDIMSampler built from that yaml (oracle/make_golden.py --eps): the oracle, and the
+    PRODUCT sampler on the oracle's op table - whose fused update takes the eps step through transformed scalars."""
+    from oracle.ops_torch import TorchOps
+    from open_pandora_amd.ddim import DDIMSampler
+    from open_pandora_amd.ddpm import LatentVisualDiffusion
+    torch.set_num_threads(4)
+    g = load("ddim_small_eps.npz")
+    want = g[f"S{S}_eta{eta:g}_cfg{cfg:g}"]
+    kw = dict(RH_KW, model_channels=64, **gr.UNET_256_OVERRIDES)
+    m = U.UNetModel(**kw).eval()
+    sd = synth.synth_state_dict(m, seed=gr.WEIGHT_SEED)
+    tables = ddim_ref.schedule_tables(zero_snr=False, dynamic_rescale=False)
+    assert np.array_equal(tables["alphas_cumprod"].float().numpy(), g["alphas_cumprod"])  # the un-rescaled schedule, bit for bit
+    ins, cond, uc = gr.sampler_inputs(8, 8)
+    apply = lambda x, t, c, fs: unet_ref.unet_forward(sd, torch.cat([x] + c["c_concat"], 1), t, torch.cat(c["c_crossattn"], 1), fs,
+                                                      model_channels=64)
+    ns = gr.noises(ins["x_T"].shape, S)
+    y, _ = ddim_ref.ddim_sample(apply, tables, ins["x_T"], cond, uc, S, eta, cfg, noises=ns, fs=torch.tensor([3]),
+                                parameterization="eps")
+    assert rel(y, want) < 5e-5
+    m.load_state_dict(sd)
+    pm = LatentVisualDiffusion(m.bind(TorchOps()), parameterization="eps", rescale_betas_zero_snr=False, use_dynamic_rescale=False,
+                               image_size=(32, 32))
+    y2, _ = DDIMSampler(pm).sample(S=S, batch_size=1, shape=(4, 16, 8, 8), conditioning=cond, verbose=False,
+                                   unconditional_guidance_scale=cfg, unconditional_conditioning=uc, eta=eta, fs=torch.tensor([3]),
+                                   timestep_spacing="uniform_trailing", x_T=ins["x_T"], noise_fn=lambda i, shape: ns[i])
+    assert rel(y2, want) < 5e-5

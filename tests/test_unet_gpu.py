@@ -32,6 +32,11 @@ TRAJ_TOL = {k: v * CFG_AMPLIFICATION for k, v in FWD_TOL.items()}
 TRAJ_TOL_REDUCED = {k: v * CFG_AMPLIFICATION for k, v in FWD_TOL_REDUCED.items()}
 
 
+# eps-parameterised trajectories (256 yaml), reduced width: 1.3 x measured (1.72e-3 / 1.35e-2 at 5 steps cfg 4, 3.40e-3 / 2.71e-2 at
+# 20 steps cfg 7.5; f16 / bf16) - inside the v-models' reduced-width trajectory bounds (5.6e-3 / 4.4e-2) as well
+EPS_TRAJ_TOL = {(5, torch.float16): 2.3e-3, (5, torch.bfloat16): 1.8e-2, (20, torch.float16): 4.5e-3, (20, torch.bfloat16): 3.6e-2}
+
+
 def small_model(mc, ops):
     m = UNetModel(**dict(RH_KW, model_channels=mc)).eval()
     m.load_state_dict(synth.synth_state_dict(m, seed=gr.WEIGHT_SEED))
@@ -65,6 +70,30 @@ def test_unet_small_forward_learnable_image_attention_scale(hip_ops_factory, dty
     err = rel(y.cpu(), g)
     print(f"\n[parity] unet_small 256-yaml (learnable image scale) {tag} {dtype}: rel err {err:.2e}")
     assert err <= FWD_TOL_REDUCED[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("S,eta,cfg", gr.DDIM_EPS_CASES)
+def test_ddim_eps_parameterisation_trajectory(hip_ops_factory, dtype, S, eta, cfg):
+    """The 256 yaml's sampler path on the kernels (eps-prediction through the fused update's transformed scalars, un-rescaled
+    schedule, the learnable image-attention scale in the U-Net) against the REAL reference built from that yaml
+    (tests/golden/ddim_small_eps.npz).  The eps update divides by sqrt(a_t) (14.6 at t = 999 without the zero-terminal-SNR
+    rescale): the trajectory amplifies forward errors more than the v-models' - tolerance = 1.3 x measured."""
+    g = load("ddim_small_eps.npz")[f"S{S}_eta{eta:g}_cfg{cfg:g}"]
+    m = UNetModel(**dict(RH_KW, model_channels=64, **gr.UNET_256_OVERRIDES)).eval()
+    m.load_state_dict(synth.synth_state_dict(m, seed=gr.WEIGHT_SEED))
+    pm = LatentVisualDiffusion(m.bind(hip_ops_factory(dtype)), parameterization="eps", rescale_betas_zero_snr=False,
+                               use_dynamic_rescale=False, image_size=(32, 32))
+    ins, cond, uc = gr.sampler_inputs(8, 8)
+    ns = gr.noises(ins["x_T"].shape, S)
+    dev = lambda c: {k: [v.cuda() for v in lst] for k, lst in c.items()}
+    y, _ = DDIMSampler(pm).sample(S=S, batch_size=1, shape=(4, 16, 8, 8), conditioning=dev(cond), verbose=False,
+                                  unconditional_guidance_scale=cfg, unconditional_conditioning=dev(uc), eta=eta,
+                                  fs=torch.tensor([3]).cuda(), timestep_spacing="uniform_trailing", x_T=ins["x_T"].cuda(),
+                                  noise_fn=lambda i, shape: ns[i])
+    err = rel(y.cpu(), g)
+    print(f"\n[parity] ddim eps-parameterisation (256 yaml) S={S} eta={eta} cfg={cfg} {dtype}: rel err {err:.2e}")
+    assert err <= EPS_TRAJ_TOL[(S, dtype)]
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
