@@ -73,6 +73,10 @@ class LatentVisualDiffusion(nn.Module):
         if use_dynamic_rescale:
             arr = np.concatenate((np.linspace(1.0, base_scale, turning_step), np.full(self.num_timesteps, base_scale)))
             self.register_buffer("scale_arr", torch.tensor(arr, dtype=torch.bfloat16))
+        # the training objective's constants at their class defaults (ddpm3d.py:48-71,101-117): plain l2 on the prediction
+        # target, no learned log-variance, no ELBO term
+        self.loss_type, self.l_simple_weight, self.original_elbo_weight, self.learn_logvar = "l2", 1.0, 0.0, False
+        self.logvar = torch.zeros(self.num_timesteps)
 
     @property
     def device(self):
@@ -113,6 +117,34 @@ class LatentVisualDiffusion(nn.Module):
 
     def predict_eps_from_z_and_v(self, x_t, t, v):
         return self._coef(self.sqrt_alphas_cumprod, t, x_t) * v + self._coef(self.sqrt_one_minus_alphas_cumprod, t, x_t) * x_t
+
+    # -- training seam (model.py:926-942 -> LatentDiffusion.forward / p_losses, ddpm3d.py:700-705,741-797) -----------------------
+    def get_v(self, x, noise, t):
+        return self._coef(self.sqrt_alphas_cumprod, t, x) * noise - self._coef(self.sqrt_one_minus_alphas_cumprod, t, x) * x
+
+    def forward(self, x, c, **kwargs):
+        """`loss, loss_dict = self.diffusion_model(x, c, fs=...)` of WorldModel.training_step: a uniformly drawn timestep per
+        clip, the dynamic rescale of x (the 512 / 1024 models), then p_losses.  The U-Net below runs its differentiable walk
+        (unet_train) whenever autograd is on and the module is in training mode."""
+        t = torch.randint(0, self.num_timesteps, (x.shape[0],), device=self.device).long()
+        if self.use_dynamic_rescale:
+            x = x * self._coef(self.scale_arr, t, x)
+        return self.p_losses(x, c, t, **kwargs)
+
+    def p_losses(self, x_start, cond, t, noise=None, **kwargs):
+        noise = torch.randn_like(x_start) if noise is None else noise
+        x_noisy = self.q_sample(x_start=x_start, t=t, noise=noise)
+        model_output = self.apply_model(x_noisy, t, cond, **kwargs)
+        prefix = "train" if self.training else "val"
+        target = noise if self.parameterization == "eps" else self.get_v(x_start, noise, t)
+        loss_simple = torch.nn.functional.mse_loss(target, model_output, reduction="none").mean([1, 2, 3, 4])
+        if torch.isnan(loss_simple).any():  # (ddpm3d.py:770-774: NaN clips are zeroed, not propagated)
+            loss_simple = torch.where(torch.isnan(loss_simple), torch.zeros_like(loss_simple), loss_simple)
+        loss_dict = {f"{prefix}/loss_simple": loss_simple.mean()}
+        logvar_t = self.logvar.to(loss_simple.device)[t]
+        loss = self.l_simple_weight * (loss_simple / torch.exp(logvar_t) + logvar_t).mean()
+        loss_dict[f"{prefix}/loss"] = loss
+        return loss, loss_dict
 
     def q_sample(self, x_start, t, noise=None):
         noise = torch.randn_like(x_start) if noise is None else noise

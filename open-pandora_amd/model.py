@@ -75,6 +75,23 @@ class WorldModel:
                                    output_attentions=None, output_hidden_states=None):
         return self._conditioner(input_ids, pixel_values, attention_mask, return_dict, output_attentions, output_hidden_states)
 
+    # -- training surface (model.py:926-974; the Lightning trainer around it is out of scope) ---------------------------------
+    def training_step(self, batch, batch_idx):
+        """model.py:926-942 (`do_alignment` False: the diffusion objective): `get_batch_input` - the LLM side + first-stage encode
+        of the batch, injected as `self.get_batch_input` - then `loss, loss_dict = self.diffusion_model(x, c, fs=fs.long())`
+        (LatentVisualDiffusion.forward -> p_losses; the U-Net takes its differentiable walk).  -> loss; the dictionary the
+        reference hands to `log_dict` is kept as `self.last_loss_dict`."""
+        del batch_idx
+        x, c, fs = self.get_batch_input(**batch, random_uncond=False)
+        loss, self.last_loss_dict = self.diffusion_model(x, c, fs=fs.long())
+        return loss
+
+    def configure_optimizers(self):
+        """model.py:951-974 (`do_alignment` False): AdamW over `diffusion_model.model.parameters()` (the DiffusionWrapper = the
+        U-Net's 1516 tensors) plus the LLM-side bridge parameters handed in as `self.extra_trainable`; lr from `config`."""
+        params = list(self.diffusion_model.model.parameters()) + list(getattr(self, "extra_trainable", []))
+        return torch.optim.AdamW(params, lr=self.config.learning_rate)
+
     def get_latent_z(self, model, videos):
         """model.py:690-701 (`model` = the diffusion model, kept for the signature)."""
         del model

@@ -233,3 +233,38 @@ def test_documented_stub_matches_capi_and_header():
         depth -= ch in ")]"
         n += (ch == "," and depth == 0)
     assert n == counts["pm_gemm"] == 19
+
+
+@needs_ref
+def test_training_step_surface_equals_the_reference_shell():
+    """WorldModel.training_step -> `self.diffusion_model(x, c, fs=...)` (model.py:926-942 -> ddpm3d.py:700-705,741-797): the
+    PRODUCT shell's forward / p_losses (timestep draw, dynamic rescale of x, q_sample, v-target, l2 mean, loss_dict keys) against
+    the REAL LatentVisualDiffusion holding the same U-Net weights, same RNG seed -> same t and noise: loss and loss_dict equal to
+    1e-6, gradients flow to the U-Net parameters; configure_optimizers builds the reference's AdamW parameter list."""
+    from open_pandora_amd import model as M
+    from open_pandora_amd.ddpm import LatentVisualDiffusion
+    ref = _no_dropout(rh.reference_diffusion(dict(model_channels=64))).train()
+    ru = ref.model.diffusion_model
+    sd = synth.synth_state_dict(ru, seed=gr.WEIGHT_SEED)
+    ru.load_state_dict(sd)
+    m = _no_dropout(UNetModel(**dict(RH_KW, model_channels=64)))
+    m.load_state_dict(sd)
+    pm = LatentVisualDiffusion(m).train()
+    ins, cond, _ = gr.sampler_inputs(8, 8)
+    x0 = ins["x_T"] * 0.18215
+    torch.manual_seed(1234)
+    want, want_d = ref(x0, cond, fs=torch.tensor([15]))
+    runner = type("R", (), {"diffusion_model": pm, "encode_first_stage": None})()
+    wmod = M.WorldModel(runner, lambda *a: None, config=type("C", (), {"learning_rate": 1e-5})())
+    wmod.get_batch_input = lambda random_uncond=False, **batch: (batch["x"], batch["c"], batch["fs"])
+    torch.manual_seed(1234)
+    got = wmod.training_step({"x": x0, "c": cond, "fs": torch.tensor([15.0])}, 0)
+    assert got.requires_grad and abs(float(got.detach()) - float(want.detach())) <= 1e-6 * abs(float(want.detach()))
+    assert set(wmod.last_loss_dict) == set(want_d) == {"train/loss_simple", "train/loss"}
+    assert all(abs(float(wmod.last_loss_dict[k].detach()) - float(want_d[k].detach())) <= 1e-6 * abs(float(want_d[k].detach()))
+               for k in want_d)
+    got.backward()
+    assert sum(p.grad is not None and float(p.grad.abs().sum()) > 0 for p in m.parameters()) > 1400
+    opt = wmod.configure_optimizers()
+    assert isinstance(opt, torch.optim.AdamW) and len(opt.param_groups[0]["params"]) == len(list(m.parameters())) == 1516
+    assert opt.param_groups[0]["lr"] == 1e-5
