@@ -258,15 +258,21 @@ def test_frames_full_width_576x1024_bf16_default_mode(hip_ops_factory):
 
 
 @pytest.mark.slow
-def test_multiround_driver_5_rounds_576x1024_full_width():
-    """BASELINE configs[4]'s driver at FULL size under pytest (it ran only in bench.py --multiround): 5
+@pytest.mark.parametrize("fp8", [False, True], ids=["bf16_attention", "fp8_attention"])
+def test_multiround_driver_5_rounds_576x1024_full_width(fp8):
+    """BASELINE configs[4]'s driver at FULL size under pytest - with the spatial self-attention of levels 0-1 on the fp8 (e4m3)
+    MFMA kernel too, which is configs[4]'s named configuration (it ran only in bench.py --multiround): 5
     autoregressive rounds at 576x1024 on the 1.44 B U-Net + the full AutoencoderKL in bf16, 4 DDIM steps per round (the loop
     length is not what this exercises).  Shape (1, 1, 3, 12 x 4 + 16, 576, 1024), finite (the decoder of the seeded weights overshoots [-1, 1]: |x| < 10); round 1's frames are
     the single-round `generate` of the same inputs bit for bit; every later round was conditioned on the previous round's last
     4 frames through the 8-bit round trip (model.py:1179-1187) - the encoder saw 1, 4, 4, 4, 4 frames."""
     from open_pandora_amd import factory
     from open_pandora_amd.ops_hip import HipOps
-    ops = HipOps(torch.bfloat16, "cuda:0")
+    ops = HipOps(torch.bfloat16, "cuda:0", fp8_attention=fp8)
+    fp8_calls = [0]
+    if fp8:
+        inner = ops.attention_fp8
+        ops.attention_fp8 = lambda *a, **k: (fp8_calls.__setitem__(0, fp8_calls[0] + 1), inner(*a, **k))[1]
     pm = factory.build_diffusion("576x1024", ops, seed=gr.WEIGHT_SEED)
     ae = AutoencoderKL()
     ae.load_state_dict(synth.synth_state_dict(ae, seed=gr.WEIGHT_SEED))
@@ -291,7 +297,9 @@ def test_multiround_driver_5_rounds_576x1024_full_width():
     single = run.generate(texts[0], frame0, frame0[None, :, 0], **kw)
     assert torch.equal(video[0, 0][:, :12], single[0, 0][:, :12])
     stds = [float(video[0, 0][:, 12 * r:12 * r + 12].float().std()) for r in range(5)]
-    print(f"\n[parity] multiround FULL width 5 rounds x 576x1024 bf16: 64 frames, per-round frame std {['%.3f' % s for s in stds]}")
+    assert (fp8_calls[0] > 0) == fp8  # (warm-up / capture forwards walk the op table: levels 0 and 1 take the fp8 kernel)
+    print(f"\n[parity] multiround FULL width 5 rounds x 576x1024 bf16{' + fp8 attention (levels 0-1)' if fp8 else ''}: 64 frames, "
+          f"per-round frame std {['%.3f' % s for s in stds]}")
     assert all(0.05 < s < 1.5 for s in stds)
     run.sampler.close()
     del pm, ae
