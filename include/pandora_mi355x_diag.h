@@ -26,6 +26,10 @@ void pm_debug_attn_variant(int variant);
  * `buf`: device memory of >= 16 bytes x grid size, read by nothing else.  NULL switches the stamps off. */
 void pm_debug_attn_stamps(void* buf);
 
+/* The epilogues' erf / GELU approximant (csrc/common.hpp: Q(t) = 2^P(t), r06) element by element over n f32 values:
+ * mode 0 = erf(x), mode 1 = gelu(x) = 0.5 x (1 + erf(x / sqrt 2)) (attention.py:415-430, F.gelu).  Returns a PM_* code. */
+int pm_debug_erf(const float* x, float* y, int64_t n, int mode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,18 +76,29 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
 __device__ __forceinline__ float silu_f(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
-// erf-GELU (attention.py:422, F.gelu default).  erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7,
-// f32-level): one v_exp, one v_rcp and 6 FMAs instead of libm's branchy erff - the GEGLU epilogue runs
-// it on every element of the widest GEMM output of each transformer block.
+// erf-GELU (attention.py:422, F.gelu default): gelu(x) = x Phi(x) = relu(x) - |x| Q(|x|), Q(t) = 0.5 erfc(t / sqrt 2).
+// r06: Q(t) = 2^P(t) with P a degree-5 weighted-minimax fit of log2 Q on t >= 0 (weights = what an error of
+// P costs in erf and in gelu; tools/erf_fit.py): |erf error| <= 9e-7, |gelu error| <= 8e-7 over the reals (P -> -inf, so the
+// tail is exactly relu), ONE transcendental (v_exp_f32) and 8 full-rate ops - the Abramowitz-Stegun 7.1.26 form it replaces
+// (v_exp + v_rcp + 14 ops, 1.5e-7) cost as many issue cycles per element as the whole K = 320 MFMA loop of a GEGLU tile.
+// NaN propagates (relu as h + |h|); x = +-inf gives NaN (inf * 0) where the old form gave +inf / -0.
+__device__ __forceinline__ float gelu_q_exp2(float t) {  // log2 of 0.5 erfc(t / sqrt 2), t >= 0
+  float p = fmaf(-0.0005101419295911639f, t, 0.007342507309409537f);
+  p = fmaf(p, t, -0.052463149158147024f);
+  p = fmaf(p, t, -0.45932433014520657f);
+  p = fmaf(p, t, -1.151073326450374f);
+  return fmaf(p, t, -1.0000011294044768f);
+}
 __device__ __forceinline__ float gelu_erf_f(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  const float e = 1.0f - poly * t * __expf(-z * z);  // erf(|x| / sqrt 2)
-  return 0.5f * x + 0.5f * fabsf(x) * e;              // 0.5 x (1 + sign(x) erf(|x|/sqrt2))
+  const float t = fabsf(x);
+  const float q = __builtin_amdgcn_exp2f(gelu_q_exp2(t));
+  const float h = 0.5f * x;
+  return fmaf(-t, q, h + fabsf(h));
+}
+// erf itself through the same fit (tests: pm_debug_erf against an f64 erf, max abs <= 1e-5)
+__device__ __forceinline__ float erf_fast_f(float z) {
+  const float q = __builtin_amdgcn_exp2f(gelu_q_exp2(fabsf(z) * 1.41421356237309504880f));
+  return copysignf(fmaf(-2.0f, q, 1.0f), z);
 }
 
 __device__ __forceinline__ u32x4 ld_global16(const void* p) {

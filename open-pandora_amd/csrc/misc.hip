@@ -347,3 +347,20 @@ extern "C" int pm_unpack_output(const void* y, void* out, int64_t C, int64_t F, 
                                        (hipStream_t)stream, (const T*)y, (T*)out, (int)C, FP);
                     return check_launch());
 }
+
+#ifdef PM_DIAG
+// diagnostics: the epilogues' erf / GELU approximants, element by element (mode 0: erf_fast_f, 1: gelu_erf_f) - the op-level
+// test of common.hpp's fit against an f64 erf (tests/test_ops_gpu.py::test_erf_approximant)
+namespace pm {
+__global__ void debug_erf_kernel(const float* x, float* y, long n, int mode) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = mode ? gelu_erf_f(x[i]) : erf_fast_f(x[i]);
+}
+}  // namespace pm
+extern "C" int pm_debug_erf(const float* x, float* y, int64_t n, int mode, void* stream) {
+  if (!x || !y) return PM_E_NULL;
+  if (n < 1) return PM_E_SHAPE;
+  hipLaunchKernelGGL(pm::debug_erf_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, mode);
+  return pm::check_launch();
+}
+#endif

@@ -24,6 +24,7 @@ from oracle import golden_recipe as gr  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 WEIGHT_SEED, INPUT_SEED, NOISE_SEED = gr.WEIGHT_SEED, gr.INPUT_SEED, gr.NOISE_SEED
+SUFFIX = ""  # --heldout-seeds: appended to the fixture names of gen_frames_full
 
 
 def digest(t, n=4096):
@@ -546,8 +547,10 @@ def gen_frames_full(cases, h=40, w=64, forwards=False):
         out["frames/per_frame_std"] = frames[0].double().std(dim=(0, 2, 3)).numpy()
         out["wall_seconds"] = np.float64(dt)
         out["threads"] = np.int64(torch.get_num_threads())
-        save(f"frames_full_{h}x{w}_s{S}_eta{eta:g}.npz", **out)
-        if eta == 0 and (h, w, S) in ((40, 64, 10), (72, 128, 2)):
+        if SUFFIX:
+            out["weight_seed"], out["input_seed"] = np.int64(WEIGHT_SEED), np.int64(gr.INPUT_SEED)
+        save(f"frames_full_{h}x{w}_s{S}_eta{eta:g}{SUFFIX}.npz", **out)
+        if eta == 0 and (h, w, S) in ((40, 64, 10), (72, 128, 2)) and not SUFFIX:
             out = {"source": np.array(src), "wall_seconds": np.float64(dt), "threads": np.int64(torch.get_num_threads())}
             for k, v in digest(z).items():
                 out[f"sample/{k}"] = v
@@ -574,7 +577,13 @@ if __name__ == "__main__":
     ap.add_argument("--frames-full", default="", help='full-width cases "S:eta,S:eta", e.g. "10:0,50:1" (hours of CPU)')
     ap.add_argument("--frames-full-72x128", default="", help='the same at 16x72x128 -> 576x1024 frames, e.g. "2:0"')
     ap.add_argument("--with-forwards", action="store_true", help="--frames-full*: also the single-forward fixtures unet_full_*")
+    ap.add_argument("--heldout-seeds", default="", help='"W:I": other weight / input seeds for --frames-full* (r06: the held-out '
+                    'fixture the selective-parity site list is NOT tuned on); files get the suffix _w<W>_i<I>')
     a = ap.parse_args()
+    if a.heldout_seeds:
+        assert a.frames_full or a.frames_full_72x128, "--heldout-seeds goes with --frames-full*"
+        WEIGHT_SEED, gr.INPUT_SEED = (int(v) for v in a.heldout_seeds.split(":"))
+        SUFFIX = f"_w{WEIGHT_SEED}_i{gr.INPUT_SEED}"
     if a.frames or a.frames_full or a.frames_full_72x128:
         assert rh.available()
         if a.frames:
