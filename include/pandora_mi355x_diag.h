@@ -26,6 +26,13 @@ void pm_debug_attn_variant(int variant);
  * `buf`: device memory of >= 16 bytes x grid size, read by nothing else.  NULL switches the stamps off. */
 void pm_debug_attn_stamps(void* buf);
 
+/* Kernel choice of pm_gemm for the 256x256 assembly-loop kernel (csrc/gemm_wide.hip): 0 = never, 1 = by its rule (initial value,
+ * unless PANDORA_GEMM_WIDE is set), 2 = wherever it is legal.  Process-wide: measurement runs and the forced-kernel parity tests. */
+void pm_debug_gemm_wide(int mode);  /* (+ 16 x loop variant of tools/gen_wide_loop.py VARIANTS: timing-only ablations, 7 = stamps) */
+/* In-kernel stamps of gemm_wide's loop variant 7: per workgroup b, buf[8 b + 0..6] = shader cycles in the tile prologues / K loops /
+ * epilogues, -, K-steps walked, end-of-kernel s_memtime and s_memrealtime.  `buf`: device memory of 64 bytes x grid size; NULL = off. */
+void pm_debug_wide_stamps(void* buf);
+
 /* The epilogues' erf / GELU approximant (csrc/common.hpp: Q(t) = 2^P(t), r06) element by element over n f32 values:
  * mode 0 = erf(x), mode 1 = gelu(x) = 0.5 x (1 + erf(x / sqrt 2)) (attention.py:415-430, F.gelu).  Returns a PM_* code. */
 int pm_debug_erf(const float* x, float* y, int64_t n, int mode, void* stream);

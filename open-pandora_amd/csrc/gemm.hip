@@ -359,7 +359,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     }
     // ---------------- epilogue: registers -> global (no LDS staging, no barrier) ----------------
     // split-K slices store raw f32 partials into their slab; bias/act/residual run in the reduce pass
-    epilogue_regs<T>(p, acc, bv, m0, n0, wm, wn, fr, fq, mt * WMW + wm, split, res_done);
+    // (r06: the 16-bit projection flavours - q|k|v with its column scale, plain / bias - on the lean epilogue where the wave's
+    // 64 x 64 piece lies inside the matrix: gemm_common.hpp epilogue_lean16)
+    if (AMODE == A_DENSE && !res_done && epilogue_lean16_ok(p, m0 + wm * 64, n0 + wn * 64))
+      epilogue_lean16<T>(p, acc, bv, m0 + wm * 64, n0 + wn * 64, fr, fq);
+    else
+      epilogue_regs<T>(p, acc, bv, m0, n0, wm, wn, fr, fq, mt * WMW + wm, split, res_done);
     if (!has_next) break;
     w += G;
     __syncthreads();  // the prefetched first K-tile of item w has landed (vmcnt drained here, behind the stores)
@@ -744,7 +749,10 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
 #endif
 
     // ---------------- epilogue of this wave's 64x64 quadrant (the loaders keep streaming the next tile) ----
-    epilogue_regs<T>(p, acc, bv, m0, n0, wm, wn, fr, fq, mt * 2 + wm, split, res_done);
+    if (AMODE == A_DENSE && !res_done && epilogue_lean16_ok(p, m0 + wm * 64, n0 + wn * 64))
+      epilogue_lean16<T>(p, acc, bv, m0 + wm * 64, n0 + wn * 64, fr, fq);  // (r06: see gemm_kernel)
+    else
+      epilogue_regs<T>(p, acc, bv, m0, n0, wm, wn, fr, fq, mt * 2 + wm, split, res_done);
 #ifdef PM_RING_PROF
     t_epi += clock64() - e0;
 #endif
@@ -1135,8 +1143,13 @@ __global__ __launch_bounds__(512, 1) void gemm_ringw_kernel(const GemmParams p) 
     {
       if constexpr (AMODE != A_DENSE) load_bias_regs(p, bv, n0, wn, fq);
       const int m_eff = m0 + wm * 128;
-      epilogue_regs<T>(p, acc0, bv, m_eff, n0, 0, wn, fr, fq, m_eff >> 6, split, res_done);
-      epilogue_regs<T>(p, acc1, bv, m_eff + 64, n0, 0, wn, fr, fq, (m_eff + 64) >> 6, split, res_done);
+      if (AMODE == A_DENSE && !res_done && epilogue_lean16_ok(p, m_eff, n0 + wn * 64) && m_eff + 128 <= p.M) {
+        epilogue_lean16<T>(p, acc0, bv, m_eff, n0 + wn * 64, fr, fq);  // (r06: see gemm_kernel)
+        epilogue_lean16<T>(p, acc1, bv, m_eff + 64, n0 + wn * 64, fr, fq);
+      } else {
+        epilogue_regs<T>(p, acc0, bv, m_eff, n0, 0, wn, fr, fq, m_eff >> 6, split, res_done);
+        epilogue_regs<T>(p, acc1, bv, m_eff + 64, n0, 0, wn, fr, fq, (m_eff + 64) >> 6, split, res_done);
+      }
     }
 #ifdef PM_RING_PROF
     t_epi += clock64() - e0;
@@ -1575,6 +1588,8 @@ extern "C" int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, c
   if (K % BK) return PM_E_SHAPE;  // all Linear layers on the path have K % 64 == 0
   plan_split(p, workspace, workspace_bytes);
   if (p.colstats != nullptr && p.splits > 1 && ((p.ldc & 3) || (p.R != nullptr && (p.ldr & 3)))) return PM_E_SHAPE;
+  // wide / long-K shapes whose grid keeps whole rounds of 256 x 256 tiles: four waves of 128 x 128, assembly main loop (gemm_wide.hip)
+  if (gemm_wide_wanted(p, flags, num_cus())) PM_DISPATCH_DTYPE(dtype, T, return (launch_gemm_wide<T>(p, num_cus(), (hipStream_t)stream)));
   // large MFMA-bound shapes: 256x256 tiles, 8-phase ping-pong (gemm256.hip) - where the 256x128 ring kernel is not preferred
   if (!(g_ringw == 1 && g_ring != 0 && !(flags & PM_FLAG_A_F32) && prefer_ringw(A_DENSE, p)) && !(g_ringw == 2 && g_ring == 2) &&
       gemm256_wanted(p, flags, num_cus()))

@@ -495,8 +495,82 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, f32x4 (&acc)[
   }
 }
 
+// LEAN epilogue of the 16-bit projection flavours (r06).  In-kernel stamps of gemm_wide with every store masked off
+// (profiles/r06/wide_kernel_stamps.txt): epilogue_regs above costs ~3700 cycles of pure instruction issue per 64 x 64 piece and wave
+// - ~900 issue slots for 64 values per lane: every flavour lives behind runtime branches, every store behind its own exec-mask
+// branch, every row address is a 64-bit multiply, and the kernel's spilled scalars come back through v_readlane chains.  The
+// flavours that make up the wide projections (q|k|v with its per-column scale, GEGLU, plain / bias; 16-bit output, no residual, no
+// statistics, unsplit) need none of that when the piece lies wholly inside the matrix: one base pointer per lane, a constant row
+// step, straight-line arithmetic, unconditional 16-byte (GEGLU: 8-byte) stores.  Caller checks `epilogue_lean16_ok`.
+__device__ __forceinline__ bool epilogue_lean16_ok(const GemmParams& p, int m_p, int n_p) {
+  if (p.splits > 1 || p.out32 || p.R != nullptr || p.colstats != nullptr) return false;
+  if (m_p + 64 > p.M || n_p + 64 > p.N) return false;
+  if (p.act == PM_ACT_GEGLU) return (p.ldc & 3) == 0 && (p.N & 7) == 0;
+  return p.act == PM_ACT_NONE && !p.natural && (p.ldc & 7) == 0;
+}
+template <typename T, bool NOSTORE = false>  // (NOSTORE: diagnostics, timing only)
+__device__ __forceinline__ void epilogue_lean16(const GemmParams& p, f32x4 (&acc)[4][4], const float (&bv)[4][4], int m_p, int n_p,
+                                                int fr, int fq) {
+  const int64_t rstep = (int64_t)16 * p.ldc;
+  if (p.act == PM_ACT_GEGLU) {
+    // value block 2jj, gate block 2jj+1 (weights packed [16 value | 16 gate]): 4 adjacent output columns per lane and pair
+    T* rp = reinterpret_cast<T*>(p.C) + (int64_t)(m_p + fr) * p.ldc + (n_p >> 1) + 4 * fq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        Pack4<T> ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          ov.e[r] = from_f32<T>((acc[i][2 * jj][r] + bv[2 * jj][r]) * gelu_erf_f(acc[i][2 * jj + 1][r] + bv[2 * jj + 1][r]));
+        *reinterpret_cast<u32x2*>(rp + jj * 16) = ov.u;
+      }
+      rp += rstep;
+    }
+    return;
+  }
+  // interleaved W rows (cperm): the block pair (2jp, 2jp+1) is 8 ADJACENT columns jp*32 + fq*8 .. +7
+  T* rp = reinterpret_cast<T*>(p.C) + (int64_t)(m_p + fr) * p.ldc + n_p + 8 * fq;
+  if (p.bias_mul) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] *= bv[j][r];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] += bv[j][r];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      Pack8<T> ov;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ov.e[r] = from_f32<T>(acc[i][2 * jp][r]);
+        ov.e[4 + r] = from_f32<T>(acc[i][2 * jp + 1][r]);
+      }
+      if constexpr (NOSTORE)
+        asm volatile("" ::"v"(ov.u), "v"(rp));
+      else
+        st_global16(rp + jp * 32, ov.u);
+    }
+    rp += rstep;
+  }
+}
+
 // gemm256.hip: the 256x256 8-phase kernel for large dense shapes
 bool gemm256_wanted(const GemmParams& p, int flags, int num_cus);
 template <typename T> int launch_gemm256(const GemmParams& p, int num_cus, hipStream_t stream);
+
+// gemm_wide.hip: 256x256 tile, four waves of 128x128, assembly main loop (r06)
+bool gemm_wide_wanted(const GemmParams& p, int flags, int num_cus);
+template <typename T> int launch_gemm_wide(const GemmParams& p, int num_cus, hipStream_t stream);
 
 }  // namespace pm

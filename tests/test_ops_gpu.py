@@ -272,6 +272,51 @@ def test_conv_temporal(hip_ops_factory, dtype, F, P, C, halo):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_wide_256x256_asm_loop(hip_ops_factory, dtype):
+    """gemm_wide_kernel (csrc/gemm_wide.hip, r06: 256x256 tile, four waves of 128x128, generated assembly main loop with the
+    accumulators fixed in a[0:255]), FORCED on every legal call through the diagnostics build (pm_debug_gemm_wide(2)) and checked
+    against the other kernels of pm_gemm on the same inputs: exact-integer products (ragged last row / column tiles, K loops of
+    2, 3 and 21 steps = both exits of the unrolled loop), every epilogue flavour incl. the lean 16-bit one (bias, per-column
+    scale, GEGLU), f32 stream + f32 residual + fused GroupNorm statistics; and the library's own rule picks it for a long-K
+    shape (choice of the shipped library: pm_gemm at K = 4096 on 4096 x 4096)."""
+    ops = hip_ops_factory(dtype, diag=True)
+    g = torch.Generator().manual_seed(5)
+    try:
+        for M, N, K in [(777, 1000, 128), (512, 512, 192), (1300, 520, 1344)]:
+            a = torch.randint(-3, 4, (M, K), generator=g).to(dtype)
+            w = torch.randint(-3, 4, (N, K), generator=g).to(dtype)
+            w[:, 1::3] *= 0
+            want = (a.float() @ w.float().t()).to(dtype).float()
+            ops.lib.pm_debug_gemm_wide(2)
+            assert torch.equal(ops.gemm(a.cuda(), w.cuda()).float().cpu(), want), (M, N, K)
+        M, N, K = 1024, 768, 1280
+        a, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=2)
+        bias, res = rnd(N, dtype=torch.float32, seed=3), rnd(M, N, dtype=dtype, seed=4)
+        scale = rnd(N, dtype=torch.float32, seed=8).abs() + 0.5
+        res32 = rnd(M, N, dtype=torch.float32, seed=5)
+        da, dw, db, dr = dev(a, w, bias, res)
+        wgp, bgp = packing.pack_geglu(w, bias)
+        calls = {"bias": lambda: ops.gemm(da, dw, db), "bias + res16": lambda: ops.gemm(da, dw, db, dr),
+                 "column scale": lambda: ops.gemm(da, dw, col_scale=scale.cuda()),
+                 "geglu": lambda: ops.gemm(da, wgp.cuda(), bgp.cuda(), act="geglu"),
+                 "silu": lambda: ops.gemm(da, dw, db, act="silu"),
+                 "stream + res32 + stats": lambda: ops.gemm(da, dw, db, res32.cuda(), stream=True, stats=(4, 32))}
+        for name, fn in calls.items():
+            outs = []
+            for mode in (0, 2):
+                ops.lib.pm_debug_gemm_wide(mode)
+                y = fn()
+                outs.append(y if isinstance(y, tuple) else (y, None))
+            (y0, t0), (y2, t2) = outs
+            assert rel_err(y2.float(), y0.float().cpu()) <= 2e-6 + (TOL[dtype] if y0.dtype != torch.float32 else 0), name
+            if t0 is not None:
+                assert rel_err(t2, t0.cpu()) <= 1e-5, name
+        assert rel_err(ops.gemm(da, dw, db), REF.gemm(a, w, bias, None, "none")) <= TOL[dtype]
+    finally:
+        ops.lib.pm_debug_gemm_wide(1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_ringw_256x128_tiles(hip_ops_factory, dtype):
     """gemm_ringw_kernel (the ring kernel on 256x128 tiles, csrc/gemm.hip), selected by the library's own rule
     (pm_gemm_kernel_choice == 3: unsplit, K >= 512, whole rounds of 256-row tiles): exact-integer product with a ragged last
