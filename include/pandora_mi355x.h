@@ -64,6 +64,14 @@ extern "C" {
                            * pass through the DMA-staged 16-bit kernels (K/2 % 64 == 0) */
 
 /* activation fused into a GEMM / conv epilogue */
+#define PM_FLAG_STATS_I64 64 /* GEMM family, with `colstats` != NULL (r06): `colstats` is int64_t totals [NI][32][4][8] (NI = bits 8..15 of
+                             * `flags`; M % NI == 0, rows per instance a multiple of pm_gemm_colstats_rows, N % 32 == 0) that the epilogue ADDS the
+                             * GroupNorm sums of the stored values to - per (instance, group of N/32 columns): {sum, sumsq} as two
+                             * fixed-point limbs each (2^-12 and 2^-44 units, element 0 of a 64-byte sector each; integer atomics: the totals do not depend on arrival order).
+                             * The caller zeroes the buffer; pm_groupnorm_apply reads it with PM_TOTALS_I64.  No finalize launch. */
+#define PM_TOTALS_I64 0x200 /* OR-ed into the in_dtype of pm_groupnorm_stats (totals = int64 limbs as above, added to; `partials` unused)
+                             * and into the out_dtype of pm_groupnorm_apply (totals = int64 limbs; bits 16..23 of out_dtype = nsum >= 1:
+                             * instance i uses the integer sum of entries i*nsum .. i*nsum + nsum - 1, e.g. per-frame sums -> clip sums) */
 #define PM_ACT_NONE 0
 #define PM_ACT_SILU 1
 #define PM_ACT_GEGLU 2 /* weight rows interleaved x/gate in blocks of 16 (see pm_gemm) */

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("PANDORA_LIB", DIAG_LIB_PATH if os.environ.get("PANDOR
 
 PM_F16, PM_BF16, PM_F32 = 1, 2, 3
 PM_OUT_HILO = 0x100
+PM_TOTALS_I64, PM_FLAG_STATS_I64 = 0x200, 64
 PM_FLAG_A_F32, PM_FLAG_OUT_F32, PM_FLAG_RES_F32, PM_FLAG_BIAS_IS_SCALE, PM_FLAG_A_LO, PM_FLAG_W_WRAP = 1, 2, 4, 8, 16, 32
 PM_ACT_NONE, PM_ACT_SILU, PM_ACT_GEGLU, PM_ACT_GELU = 0, 1, 2, 3
 ACT_CODES = {"none": PM_ACT_NONE, None: PM_ACT_NONE, "silu": PM_ACT_SILU, "geglu": PM_ACT_GEGLU, "gelu": PM_ACT_GELU}

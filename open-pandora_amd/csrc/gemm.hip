@@ -1278,7 +1278,31 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const GemmPara
     red[rl][cq4][2 * e + 1] = cq[e];
   }
   __syncthreads();
-  if (rl == 0 && ncol && p.colstats != nullptr) {
+  if (rl == 0 && p.colstats != nullptr && p.gs_ni > 0) {
+    // r06: GroupNorm totals by integer atomics (gemm_common.hpp).  This wave's 64 lanes hold 4 consecutive columns each, in
+    // lane order; a 4-run can straddle a group boundary (10 or 30 channels per group): the part in the run's FIRST group goes
+    // through the segmented wave sum, the rest (at most one lane per boundary) is added directly
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = ((red[0][cq4][e] + red[1][cq4][e]) + red[2][cq4][e]) + red[3][cq4][e];
+    const int cpg = p.N >> 5;
+    const int g0 = ncol ? n / cpg : -1;
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool first = (n + e) / cpg == g0;
+      s0 += first ? o[2 * e] : 0.f;
+      q0 += first ? o[2 * e + 1] : 0.f;
+      s1 += first ? 0.f : o[2 * e];
+      q1 += first ? 0.f : o[2 * e + 1];
+    }
+    long long* base = reinterpret_cast<long long*>(p.colstats) + (int64_t)(r0 / p.gs_rows) * 32 * 4 * GS_STRIDE;
+    gs_wave_add(base, s0, q0, g0, cq4);
+    if (ncol && (n + 3) / cpg != g0 && n + 3 < p.N) {
+      gs_atomic_add(base + (int64_t)(g0 + 1) * 4 * GS_STRIDE, s1);
+      gs_atomic_add(base + ((int64_t)(g0 + 1) * 4 + 2) * GS_STRIDE, q1);
+    }
+  } else if (rl == 0 && ncol && p.colstats != nullptr) {
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = ((red[0][cq4][e] + red[1][cq4][e]) + red[2][cq4][e]) + red[3][cq4][e];
@@ -1581,6 +1605,11 @@ extern "C" int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, c
   p.a_lo = (flags & PM_FLAG_A_LO) ? 1 : 0;
   p.kwrap = (flags & PM_FLAG_W_WRAP) ? (int)Kw : 0;
   p.colstats = colstats;
+  if (colstats != nullptr && (flags & PM_FLAG_STATS_I64)) {  // r06: int64 group totals [NI][32][4] instead of column sums
+    p.gs_ni = (flags >> 8) & 0xff;
+    if (p.gs_ni < 1 || (p.M % p.gs_ni) || (p.N & 31)) return PM_E_SHAPE;
+    p.gs_rows = p.M / p.gs_ni;
+  }
   p.ntiles = (int)((N + BN - 1) / BN);
   p.zero = A;  // dense K tails never occur (K % 8 == 0 and whole chunks only); see kin below
   // A dense K tail (K % 64 != 0) reads chunk-wise: chunks with k >= K take `zero`; any 16 readable
@@ -1620,6 +1649,11 @@ extern "C" int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const f
   p.out32 = (flags & PM_FLAG_OUT_F32) ? 1 : 0;
   p.res32 = (flags & (PM_FLAG_OUT_F32 | PM_FLAG_RES_F32)) ? 1 : 0;
   p.colstats = colstats;
+  if (colstats != nullptr && (flags & PM_FLAG_STATS_I64)) {  // r06: int64 group totals [NI][32][4] instead of column sums
+    p.gs_ni = (flags >> 8) & 0xff;
+    if (p.gs_ni < 1 || (p.M % p.gs_ni) || (p.N & 31)) return PM_E_SHAPE;
+    p.gs_rows = p.M / p.gs_ni;
+  }
   p.ntiles = (int)((Cout + BN - 1) / BN);
   p.Hin = (int)H; p.Win = (int)W; p.Hv = (int)Hv; p.Wv = (int)Wv; p.Cin = (int)Cin;
   p.Ho = (int)Ho; p.Wo = (int)Wo; p.stride = stride; p.ups = upsample2x ? 1 : 0; p.pad = pad_lo;
@@ -1667,6 +1701,11 @@ extern "C" int pm_conv_temporal_k3_clips(const void* x, int64_t ldx, const void*
   p.out32 = (flags & PM_FLAG_OUT_F32) ? 1 : 0;
   p.res32 = (flags & (PM_FLAG_OUT_F32 | PM_FLAG_RES_F32)) ? 1 : 0;
   p.colstats = colstats;
+  if (colstats != nullptr && (flags & PM_FLAG_STATS_I64)) {  // r06: int64 group totals [NI][32][4] instead of column sums
+    p.gs_ni = (flags >> 8) & 0xff;
+    if (p.gs_ni < 1 || (p.M % p.gs_ni) || (p.N & 31)) return PM_E_SHAPE;
+    p.gs_rows = p.M / p.gs_ni;
+  }
   p.ntiles = (int)((Cout + BN - 1) / BN);
   p.Cin = (int)Cin; p.F = (int)F; p.Fc = (int)clip_frames; p.P = (int)P; p.halo_lo = halo_lo; p.halo_hi = halo_hi;
   p.zero = zero_page;

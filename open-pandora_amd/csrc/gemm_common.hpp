@@ -30,6 +30,9 @@ struct GemmParams {
   int splits, ktps;  // split-K: number of K slices and K-tiles per slice
   float* ws;         // split-K partial slabs [splits][M][N] f32
   float* colstats;   // optional [ceil(M/64)][Nout][2]: column {sum, sum of squares} of every 64 output rows
+  // r06 (PM_FLAG_STATS_I64): `colstats` is instead int64 GroupNorm totals [NI][32 groups][4] that the epilogue ADDS to (fixed-
+  // point limbs, group_stats_add below); gs_ni = NI > 0 switches it on, gs_rows = rows per instance (a multiple of the block)
+  int gs_ni, gs_rows;
   int natural;       // W rows staged in natural column order (see cperm): GEGLU, and the all-f32 epilogue flavours
   // conv3x3
   int Hin, Win, Hv, Wv, Cin, Ho, Wo, stride, ups, pad;  // pad: zero rows/cols before the image (1, or 0)
@@ -58,6 +61,72 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + (bid >> 3);
+}
+
+// ---- GroupNorm totals by deterministic integer atomics (r06, VERDICT r05 #3a/b) -------------------------------------------------
+// The fused statistics used to leave per-(row block, column) sums behind and every consumer GroupNorm paid a finalize launch
+// (156-165 gn_finalize_colstats + 20-35 gn_finalize of ~1050 launches per forward).  A float atomic would make the totals depend
+// on arrival order; these are exact instead: a partial sum p (f32) is split into two FIXED-POINT limbs, A = rint(p 2^12) and
+// B = rint((p - A 2^-12) 2^44) (the remainder is exact in f32: |B| <= 2^31), and both are added with 64-bit INTEGER atomics -
+// associative, so the totals are bit-identical for every arrival order, every launch and every rank, and carry p's 24 bits down
+// to |p| = 2^-20 (absolute resolution 2^-44 below; range 2^50).  Totals layout: int64 [NI][groups][4][GS_STRIDE] = {sum A, sum B, sumsq A,
+// sumsq B} (each in element 0 of its 64-byte sector); the consumer (gn_apply_kernel) rebuilds sum = A 2^-12 + B 2^-44 in f64.  The buffer is zeroed by the host (one
+// memset per forward over the op table's arena, ops_hip.py).
+// Every value sits in a 64-byte sector of its own (GS_STRIDE int64s apart): the memory-side atomic unit serialises adds per
+// sector - with the 128 values of an instance packed into 1 KiB the (T,H,W) statistics of a level-0 conv (90 000 adds) cost ~9 us
+// per producer, more than the finalize launch they replace (profiles/r06/stats_i64_ab.txt).
+constexpr int GS_STRIDE = 8;
+constexpr float GS_SCALE_A = 4096.0f;                 // 2^12
+constexpr float GS_SCALE_B = 17592186044416.0f;       // 2^44
+constexpr double GS_INV_A = 1.0 / 4096.0, GS_INV_B = 1.0 / 17592186044416.0;
+__device__ __forceinline__ void gs_atomic_add(long long* dst, float p) {
+  const float a = rintf(p * GS_SCALE_A);
+  const float r = fmaf(-a, 1.0f / GS_SCALE_A, p);  // exact: p minus its rounding to the 2^-12 grid
+  const long long ia = (long long)a, ib = (long long)rintf(r * GS_SCALE_B);
+  __hip_atomic_fetch_add(dst, ia, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(dst + GS_STRIDE, ib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// One column per lane (s, q = its {sum, sum of squares}; columns in LANE ORDER, group id g non-decreasing over the lanes,
+// g < 0 = no column): segmented sum over the lanes of a group in a fixed order, then the group's first lane adds the limbs.
+__device__ __forceinline__ void gs_wave_add(long long* inst_base, float s, float q, int g, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float ts = __shfl_down(s, off, 64), tq = __shfl_down(q, off, 64);
+    const int tg = __shfl_down(g, off, 64);
+    const bool same = (lane + off < 64) && tg == g;
+    s += same ? ts : 0.f;
+    q += same ? tq : 0.f;
+  }
+  const int gp = __shfl_up(g, 1, 64);
+  if (g >= 0 && (lane == 0 || gp != g)) {
+    gs_atomic_add(inst_base + (int64_t)g * 4 * GS_STRIDE, s);
+    gs_atomic_add(inst_base + ((int64_t)g * 4 + 2) * GS_STRIDE, q);
+  }
+}
+// Epilogue form: after the xor tree every lane of quad fq holds the 16 column sums cs / cq [2][8] of its quad (replicated over
+// fr).  Lane (fr, fq) takes column index fr of them, the columns are permuted into lane order and reduced per group.
+__device__ __forceinline__ void group_stats_add(const GemmParams& p, const float (&cs)[2][8], const float (&cq)[2][8], int ncol0,
+                                                int nout, int row0, int fr, int fq, bool nat) {
+  float s = cs[0][0], q = cq[0][0];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) {
+    s = (fr == k) ? cs[k >> 3][k & 7] : s;
+    q = (fr == k) ? cq[k >> 3][k & 7] : q;
+  }
+  // this lane's column inside the wave's 64: run_col(jp, h, fq) + (e & 3) with jp = fr >> 3, e = fr & 7, h = e >> 2
+  const int lane = fr + 16 * fq;
+  // lane (fr, fq) holds column offset run_col(jp, h, fq) + (e & 3) with jp = fr >> 3, e = fr & 7, h = e >> 2 (a permutation of
+  // 0..63); lane L wants offset L.  interleaved: offset = jp*32 + fq*8 + e -> holder of c: fq = (c >> 3) & 3, fr = (c >> 5)*8 + (c & 7)
+  // natural: offset = jp*32 + h*16 + fq*4 + (e & 3) -> holder of c: fq = (c >> 2) & 3, fr = (c >> 5)*8 + ((c >> 4) & 1)*4 + (c & 3)
+  const int c = lane;
+  const int src = nat ? (((c >> 2) & 3) * 16 + (c >> 5) * 8 + ((c >> 4) & 1) * 4 + (c & 3)) : (((c >> 3) & 3) * 16 + (c >> 5) * 8 + (c & 7));
+  s = __shfl(s, src, 64);
+  q = __shfl(q, src, 64);
+  const int n = ncol0 + c;
+  const int cpg = nout >> 5;  // 32 groups
+  const int g = (n < nout) ? n / cpg : -1;
+  long long* base = reinterpret_cast<long long*>(p.colstats) + (int64_t)(row0 / p.gs_rows) * 32 * 4 * GS_STRIDE;
+  gs_wave_add(base, s, q, g, lane);
 }
 
 // Register-direct epilogue shared by both GEMM kernels.  The MFMAs run with the operands swapped (W
@@ -327,7 +396,10 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, f32x4 (&acc)[
             cq[jp][e] += __shfl_xor(cq[jp][e], o, 64);
           }
         }
-      if (fr == 0 && sblock * 64 < p.M) {  // (a ragged last tile has no second block)
+      if (p.gs_ni > 0) {  // (r06: group totals by integer atomics, no finalize launch)
+        if (sblock * 64 < p.M)
+          group_stats_add(p, cs, cq, ncol0, nout, sblock * 64, fr, fq, out32 && Rg == nullptr && p.natural != 0);
+      } else if (fr == 0 && sblock * 64 < p.M) {  // (a ragged last tile has no second block)
         const bool nat = out32 && Rg == nullptr && p.natural != 0;  // (as store_fast)
 #pragma unroll
         for (int jp = 0; jp < 2; ++jp)
@@ -480,7 +552,9 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, f32x4 (&acc)[
             cq[jp][e] += __shfl_xor(cq[jp][e], o, 64);
           }
         }
-      if (fr == 0 && sblock * 64 < p.M) {  // (a ragged last tile has no second block)
+      if (p.gs_ni > 0) {
+        if (sblock * 64 < p.M) group_stats_add(p, cs, cq, n0 + wn * 64, nout, sblock * 64, fr, fq, false);
+      } else if (fr == 0 && sblock * 64 < p.M) {  // (a ragged last tile has no second block)
 #pragma unroll
         for (int jp = 0; jp < 2; ++jp) {
           const int n = n0 + wn * 64 + jp * 32 + fq * 8;

@@ -2,7 +2,7 @@
 // SiLU (two passes: deterministic partial statistics, then apply) and LayerNorm.  All loads/stores
 // are 16 bytes per lane along the contiguous channel axis; statistics are f32.
 #include <type_traits>
-#include "common.hpp"
+#include "gemm_common.hpp"  // (gs_atomic_add / GS_INV_*: the int64 GroupNorm totals, r06)
 
 namespace pm {
 
@@ -39,7 +39,7 @@ __host__ __device__ inline int gn_threads(int CV) {
 // grid (nchunks, NI); block gn_threads(C/8); LDS [k][2][C] floats
 template <typename TI>
 __global__ void gn_stats_kernel(const TI* __restrict__ x, int64_t ldx, float* __restrict__ partials,
-                                int P, int C, int groups, int nchunks) {
+                                int P, int C, int groups, int nchunks, long long* __restrict__ gtot) {
   extern __shared__ __attribute__((aligned(16))) float sh[];
   const int CV = C >> 3;
   const int k = blockDim.x / CV;
@@ -93,7 +93,10 @@ __global__ void gn_stats_kernel(const TI* __restrict__ x, int64_t ldx, float* __
     const float* src = sh + which * C + g * cpg;
     float a = 0.f;
     for (int c = 0; c < cpg; ++c) a += src[c];
-    partials[(((int64_t)inst * nchunks + chunk) * groups + g) * 2 + which] = a;
+    if (gtot != nullptr)  // r06: straight into the int64 totals [NI][groups][4] (no finalize launch)
+      gs_atomic_add(gtot + (((int64_t)inst * groups + g) * 4 + which * 2) * GS_STRIDE, a);
+    else
+      partials[(((int64_t)inst * nchunks + chunk) * groups + g) * 2 + which] = a;
   }
 }
 
@@ -175,11 +178,13 @@ __global__ __launch_bounds__(256) void gn_finalize_colstats_kernel(const float* 
 // grid (ceil(P / rows_per_block), NI); block gn_threads(C/8) = (C/8) * k threads: a thread keeps one
 // 8-channel column (its scale/shift live in registers: no LDS, no barrier, no index division) and walks
 // rows r0 + rlane, + k, ... with four independent row loads in flight.
+// nsum > 0 (r06): `totals` are int64 fixed-point limbs [NI * nsum][groups][4] (gemm_common.hpp) and instance i uses the SUM of
+// entries i*nsum .. i*nsum + nsum-1 (per-frame sums of a clip add up to its (T,H,W) sums: exact in integers)
 template <typename TI, typename T>
 __global__ void gn_apply_kernel(const TI* __restrict__ x, int64_t ldx, const float* __restrict__ totals,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                 T* __restrict__ y, int64_t ldy, int P, int C, int groups, float inv_count,
-                                float eps, int silu, int rows_per_block, int lo_off) {
+                                float eps, int silu, int rows_per_block, int lo_off, int nsum) {
   // lo_off != 0 (PM_OUT_HILO, the parity configuration): the row is written as [hi | lo], hi = round16(v) at its
   // column, lo = round16(v - hi) lo_off columns further: a consumer GEMM / conv over 2C channels with the weights
   // repeated sees the normalised activation at ~2x the mantissa
@@ -208,15 +213,38 @@ __global__ void gn_apply_kernel(const TI* __restrict__ x, int64_t ldx, const flo
       const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + cv * 8 + 4);
       const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + cv * 8);
       const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + cv * 8 + 4);
+      int gprev = -1;
+      float mean = 0.f, rstd = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int g = (cv * 8 + e) / cpg;
-        const float a = totals[((int64_t)inst * groups + g) * 2];
-        const float b = totals[((int64_t)inst * groups + g) * 2 + 1];
-        const float mean = a * inv_count;
-        float var = b * inv_count - mean * mean;
-        if (var < 0.f) var = 0.f;
-        const float rstd = rsqrtf(var + eps);
+        if (g != gprev) {  // (a new group: at most two per 8-channel column once a group has >= 8 channels)
+          gprev = g;
+          if (nsum > 0) {
+            const long long* ti = reinterpret_cast<const long long*>(totals);
+            long long sa = 0, sb = 0, qa = 0, qb = 0;
+            for (int f = 0; f < nsum; ++f) {
+              const long long* t4 = ti + (((int64_t)inst * nsum + f) * groups + g) * 4 * GS_STRIDE;
+              sa += t4[0];
+              sb += t4[GS_STRIDE];
+              qa += t4[2 * GS_STRIDE];
+              qb += t4[3 * GS_STRIDE];
+            }
+            const double sum = (double)sa * GS_INV_A + (double)sb * GS_INV_B, sq = (double)qa * GS_INV_A + (double)qb * GS_INV_B;
+            const double md = sum * (double)inv_count;
+            double var = sq * (double)inv_count - md * md;
+            if (var < 0.0) var = 0.0;
+            mean = (float)md;
+            rstd = rsqrtf((float)var + eps);
+          } else {
+            const float a = totals[((int64_t)inst * groups + g) * 2];
+            const float bq = totals[((int64_t)inst * groups + g) * 2 + 1];
+            mean = a * inv_count;
+            float var = bq * inv_count - mean * mean;
+            if (var < 0.f) var = 0.f;
+            rstd = rsqrtf(var + eps);
+          }
+        }
         sc[e] = rstd * (e < 4 ? g0[e & 3] : g1[e & 3]);
         sh[e] = (e < 4 ? b0[e & 3] : b1[e & 3]) - mean * sc[e];
       }
@@ -417,7 +445,7 @@ static int gn_check(int64_t NI, int64_t P, int64_t C, int groups, int64_t ldx, i
 
 template <typename TI>
 static int launch_stats(const void* x, int64_t ldx, float* partials, float* totals, int64_t NI, int64_t P,
-                        int64_t C, int groups, hipStream_t stream) {
+                        int64_t C, int groups, hipStream_t stream, bool i64) {
   const int nchunks = (int)pm_groupnorm_nchunks(P, C);
   const int threads = gn_threads((int)(C >> 3));
   if (threads < 2 * groups) return PM_E_SHAPE;
@@ -425,20 +453,23 @@ static int launch_stats(const void* x, int64_t ldx, float* partials, float* tota
   dim3 grid(nchunks, (unsigned)NI);
   const size_t shmem = (size_t)k * 2 * C * sizeof(float);
   hipLaunchKernelGGL((gn_stats_kernel<TI>), grid, dim3(threads), shmem, stream, (const TI*)x, ldx,
-                     partials, (int)P, (int)C, groups, nchunks);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)NI), dim3(1024), 0, stream, partials, totals, nchunks,
-                     groups);
+                     partials, (int)P, (int)C, groups, nchunks, i64 ? reinterpret_cast<long long*>(totals) : nullptr);
+  if (!i64)
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)NI), dim3(1024), 0, stream, partials, totals, nchunks,
+                       groups);
   return check_launch();
 }
 
 extern "C" int pm_groupnorm_stats(const void* x, int64_t ldx, float* partials, float* totals, int64_t NI,
                                   int64_t P, int64_t C, int groups, int in_dtype, void* stream) {
-  if (!x || !partials || !totals) return PM_E_NULL;
+  const bool i64 = (in_dtype & PM_TOTALS_I64) != 0;  // r06: `totals` = int64 [NI][groups][4], ADDED to (zeroed by the caller)
+  in_dtype &= ~PM_TOTALS_I64;
+  if (!x || (!partials && !i64) || !totals) return PM_E_NULL;
   int rc = gn_check(NI, P, C, groups, ldx, in_dtype);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (in_dtype == PM_F32) return launch_stats<float>(x, ldx, partials, totals, NI, P, C, groups, st);
-  PM_DISPATCH_DTYPE(in_dtype, T, return launch_stats<T>(x, ldx, partials, totals, NI, P, C, groups, st));
+  if (in_dtype == PM_F32) return launch_stats<float>(x, ldx, partials, totals, NI, P, C, groups, st, i64);
+  PM_DISPATCH_DTYPE(in_dtype, T, return launch_stats<T>(x, ldx, partials, totals, NI, P, C, groups, st, i64));
 }
 
 extern "C" int pm_groupnorm_finalize_colstats(const float* colstats, float* totals, int64_t mtiles,
@@ -458,7 +489,10 @@ extern "C" int pm_groupnorm_apply(const void* x, int64_t ldx, const float* total
   int rc = gn_check(NI, P, C, groups, ldx, in_dtype);
   if (rc) return rc;
   const int lo_off = (out_dtype & PM_OUT_HILO) ? (int)C : 0;
-  out_dtype &= ~PM_OUT_HILO;
+  // r06: PM_TOTALS_I64 in out_dtype: totals are int64 limbs; bits 16..23 = nsum (entries summed per instance, >= 1)
+  const int nsum = (out_dtype & PM_TOTALS_I64) ? ((out_dtype >> 16) & 0xff) : 0;
+  if ((out_dtype & PM_TOTALS_I64) && nsum < 1) return PM_E_SHAPE;
+  out_dtype &= 0xff;
   if ((ldy & 7) || ldy < C + lo_off || count <= 0) return PM_E_SHAPE;
   const int threads = gn_threads((int)(C >> 3));
   const int k = threads / (int)(C >> 3);
@@ -469,7 +503,7 @@ extern "C" int pm_groupnorm_apply(const void* x, int64_t ldx, const float* total
                      hipLaunchKernelGGL((gn_apply_kernel<TI, TO>), grid, dim3(threads), 0,
                                         (hipStream_t)stream, (const TI*)x, ldx, totals,
                                         gamma, beta, (TO*)y, ldy, (int)P, (int)C, groups,
-                                        (float)(1.0 / count), eps, silu, (int)rpb, lo_off);
+                                        (float)(1.0 / count), eps, silu, (int)rpb, lo_off, nsum);
                      return check_launch());
 }
 

@@ -96,6 +96,15 @@ class HipOps:
         # ... per STREAM: the sampler runs the cond and the uncond forward of a step on two streams, and two
         # split-K calls in flight at once must not share their slabs
         self._workspaces = {}
+        # r06: GroupNorm totals as int64 fixed-point limbs [NI, 32, 4, 8] that the producing kernel ADDS to with integer atomics
+        # (PM_FLAG_STATS_I64 / PM_TOTALS_I64): no finalize launch between a conv and its GroupNorm (191 of ~1050 launches per
+        # forward).  The buffers come from a per-stream arena that `begin_forward` zeroes with ONE memset; outside a forward (or
+        # past its end) a call takes a fresh zeroed tensor.  "0": the column-sum + finalize form (A/B runs)
+        self.stats_i64 = os.environ.get("PANDORA_STATS_I64", "1") != "0"
+        self.stats_i64_all = os.environ.get("PANDORA_STATS_I64", "1") == "2"  # (A/B: also from the MFMA kernels' epilogues)
+        self.stats_nsum = self.stats_i64  # groupnorm_apply sums consecutive totals entries itself (per-frame -> clip sums)
+        self._arena = {}  # stream -> [int64 tensor, next free element]
+        self.arena_bytes = 16 << 20
 
     # -- helpers ---------------------------------------------------------------------------------
     def _hilo(self):
@@ -154,15 +163,55 @@ class HipOps:
     # totals [NI, groups, 2] are the {sum, sumsq} of the stored output per instance (NI consecutive row
     # blocks) and group; taken from the epilogue's column sums when every instance is a whole number of
     # 64-row blocks, else by the ordinary statistics pass over the output.
+    def begin_forward(self):
+        """Called by UNetModel at the top of a forward (on the forward's stream): zero the stream's totals arena, ONE memset."""
+        if not self.stats_i64:
+            return
+        key = self._stream()
+        ar = self._arena.get(key)
+        if ar is None:
+            ar = self._arena[key] = [torch.empty(self.arena_bytes // 8, dtype=torch.int64, device=self.device), 0]
+        ar[0].zero_()
+        ar[1] = 0
+
+    def _alloc_totals(self, NI, groups=32):
+        """zeroed int64 [NI, groups, 4, 8] (every value in a 64-byte sector of its own: csrc/gemm_common.hpp GS_STRIDE): the next
+        slice of the stream's arena (each slice is handed out once per zeroing)"""
+        n = NI * groups * 4 * 8
+        ar = self._arena.get(self._stream())
+        if ar is not None and ar[1] + n <= ar[0].numel():
+            t = ar[0][ar[1]:ar[1] + n].view(NI, groups, 4, 8)
+            ar[1] += n
+            return t
+        return torch.zeros(NI, groups, 4, 8, dtype=torch.int64, device=self.device)
+
+    @staticmethod
+    def totals_f32(tot):
+        """int64 limbs [N, groups, 4, 8] -> f32 {sum, sumsq} [N, groups, 2] (frame-sharded exchanges, tests); f32 passes through"""
+        if tot.dtype != torch.int64:
+            return tot
+        t = tot[..., 0].double()
+        return torch.stack([t[..., 0] * 2.0 ** -12 + t[..., 1] * 2.0 ** -44, t[..., 2] * 2.0 ** -12 + t[..., 3] * 2.0 ** -44],
+                           dim=-1).float()
+
     def _stats_begin(self, M, n_out, stats, K=0):
-        """-> (colstats buffer, rows per block) or None when the epilogue cannot deliver the statistics."""
+        """-> (statistics buffer, rows per block / flags) or None when the epilogue cannot deliver the statistics."""
         if stats is None:
             return None
         NI, groups = stats[0], stats[1]
         rows = self.lib.pm_gemm_colstats_rows(M, n_out, K, 0, self.ws_bytes)  # 64 unsplit, 16 from the split-K reduce
         if M % NI or (M // NI) % rows or M % rows or n_out % groups:
             return None
+        # int64 totals only where the statistics come out of the split-K REDUCE pass (rows == 16: the deep levels).  In the MFMA
+        # kernels' own epilogue the group reduction + atomics cost more than the finalize launch they save (A/B on one box, step
+        # +1.2 % / +3 % with them, profiles/r06/stats_i64_ab.txt): unsplit calls keep column sums + pm_groupnorm_finalize_colstats
+        if self.stats_i64 and groups == 32 and NI <= 255 and (rows == 16 or self.stats_i64_all):
+            return self._alloc_totals(NI, groups), -(capi.PM_FLAG_STATS_I64 | (NI << 8))  # (negative: the flag word)
         return torch.empty((M // rows) * n_out * 2, dtype=torch.float32, device=self.device), rows
+
+    @staticmethod
+    def _stats_flags(col):
+        return -col[1] if col is not None and col[1] < 0 else 0
 
     def _stats_end(self, out, col, stats):
         if stats is None:
@@ -171,6 +220,8 @@ class HipOps:
         if col is None:
             # (NI, groups, "lazy"): the caller only wants statistics that come for free from the epilogue
             return (out, None) if len(stats) > 2 else (out, self.groupnorm_stats(out, NI, groups))
+        if col[1] < 0:
+            return out, col[0]  # int64 totals: the epilogue has added to them, nothing to finalize
         buf, rows = col
         M, n_out = out.shape
         tot = torch.empty(NI, groups, 2, dtype=torch.float32, device=self.device)
@@ -213,6 +264,7 @@ class HipOps:
             assert bias is None and col_scale.dtype == torch.float32 and col_scale.numel() == N
             bias, flags = col_scale, flags | capi.PM_FLAG_BIAS_IS_SCALE
         col = self._stats_begin(M, n_out, stats, K)
+        flags |= self._stats_flags(col)
         rc = self.lib.pm_gemm(_ptr(a), self._rows(a, True), _ptr(w), w.shape[1], _ptr(bias),
                               _ptr(residual), residual.stride(0) if residual is not None else 0,
                               _ptr(out), out.stride(0), M, N, K, capi.ACT_CODES[act], flags, self.dt,
@@ -244,7 +296,7 @@ class HipOps:
         M, K = a.shape
         N = w.shape[0]
         col = self._stats_begin(M, N, stats, K)
-        flags = capi.PM_FLAG_A_F32 | capi.PM_FLAG_OUT_F32 | capi.PM_FLAG_A_LO
+        flags = capi.PM_FLAG_A_F32 | capi.PM_FLAG_OUT_F32 | capi.PM_FLAG_A_LO | self._stats_flags(col)
         rc = self.lib.pm_gemm(_ptr(a), self._rows(a, True), _ptr(w), K, 0, _ptr(y), y.stride(0), _ptr(y), y.stride(0),
                               M, N, K, capi.PM_ACT_NONE, flags, self.dt, _ptr(self.workspace), self.ws_bytes,
                               _ptr(col[0] if col else None), self._stream())
@@ -273,6 +325,7 @@ class HipOps:
         ho, wo = (hv + pad_lo - 2) // stride + 1, (wv + pad_lo - 2) // stride + 1
         flags, out = self._gemm_io(x, residual, out, F * ho * wo, cout, stream)
         col = self._stats_begin(F * ho * wo, cout, stats, 9 * cin)
+        flags |= self._stats_flags(col)
         rc = self.lib.pm_conv2d_3x3(_ptr(x), self._rows(x, True), _ptr(wp), _ptr(bias), _ptr(residual),
                                     residual.stride(0) if residual is not None else 0, _ptr(out),
                                     out.stride(0), F, H, W, cin, cout, stride, int(upsample), int(pad_lo),
@@ -296,6 +349,7 @@ class HipOps:
             assert h is None or (h.shape == (P, cin) and self._rows(h) == self._rows(x))
         flags, out = self._gemm_io(x, residual, out, F * P, cout, stream)
         col = self._stats_begin(F * P, cout, stats, 3 * cin)
+        flags |= self._stats_flags(col)
         rc = self.lib.pm_conv_temporal_k3_clips(_ptr(x), self._rows(x, True), _ptr(halo_lo), _ptr(halo_hi),
                                                 _ptr(wp), _ptr(bias), _ptr(residual),
                                                 residual.stride(0) if residual is not None else 0,
@@ -331,6 +385,12 @@ class HipOps:
         M, C = x.shape
         P = M // NI
         assert P * NI == M
+        if self.stats_i64 and groups == 32:
+            tot = self._alloc_totals(NI, groups)
+            rc = self.lib.pm_groupnorm_stats(_ptr(x), self._rows(x, True), 0, _ptr(tot), NI, P, C, groups,
+                                             self._in_dt(x) | capi.PM_TOTALS_I64, self._stream())
+            capi.check(rc, f"pm_groupnorm_stats (int64 totals) NI={NI} P={P} C={C}")
+            return tot
         nch = self.lib.pm_groupnorm_nchunks(P, C)
         part = torch.empty(NI, nch, groups, 2, dtype=torch.float32, device=self.device)
         tot = torch.empty(NI, groups, 2, dtype=torch.float32, device=self.device)
@@ -349,7 +409,12 @@ class HipOps:
             out, odt = self.empty(M, 2 * C), self.dt | capi.PM_OUT_HILO  # [hi | lo]
         if out is None:
             out = self.empty(M, C)
-        assert totals.shape == (NI, groups, 2) and totals.is_contiguous()
+        if totals.dtype == torch.int64:  # limbs [NI * nsum, groups, 4]: the kernel sums nsum consecutive entries per instance
+            nsum = totals.shape[0] // NI
+            assert totals.shape == (NI * nsum, groups, 4, 8) and totals.is_contiguous() and 1 <= nsum <= 255
+            odt |= capi.PM_TOTALS_I64 | (nsum << 16)
+        else:
+            assert totals.shape == (NI, groups, 2) and totals.is_contiguous()
         rc = self.lib.pm_groupnorm_apply(_ptr(x), self._rows(x, True), _ptr(totals), _ptr(gamma),
                                          _ptr(beta), _ptr(out), self._rows(out), NI, P, C, groups,
                                          float(count), float(eps), int(silu), self._in_dt(x), odt,
@@ -364,7 +429,7 @@ class HipOps:
         tot = totals if totals is not None else self.groupnorm_stats(x, NI, groups)
         count = None
         if stats_reduce is not None:
-            tot, count = stats_reduce(tot, (x.shape[0] // NI) * (x.shape[1] // groups))
+            tot, count = stats_reduce(self.totals_f32(tot), (x.shape[0] // NI) * (x.shape[1] // groups))
             tot = tot.contiguous()
         return self.groupnorm_apply(x, tot, gamma, beta, eps, NI, silu, count, groups, out)
 

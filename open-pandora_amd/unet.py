@@ -290,6 +290,10 @@ class UNetModel(packing.PackedWeights, nn.Module):
     def bind(self, ops, fp=None):
         """Select the op table (HipOps in production) and optional frame-parallel context."""
         self.ops, self.fp = ops, fp
+        if fp is not None and getattr(ops, "stats_i64", False):
+            # frame shards exchange f32 partial sums between ranks (frame_parallel / csrc/peer.hip): the op table goes back to
+            # the column-sum + finalize form, whose totals ARE f32 (converting the integer limbs would cost more launches)
+            ops.stats_i64 = ops.stats_nsum = False
         self.invalidate_packed()
         return self
 
@@ -407,8 +411,12 @@ class UNetModel(packing.PackedWeights, nn.Module):
                 if tot.shape[0] == need:
                     totals = tot
                 elif not per_frame and tot.shape[0] == c.F:
-                    # per-frame sums add up to the (T,H,W) sums of their clip
-                    totals = tot.sum(0, keepdim=True) if c.B == 1 else tot.view(c.B, c.T, *tot.shape[1:]).sum(1)
+                    # per-frame sums add up to the (T,H,W) sums of their clip: by the apply kernel itself where the op table
+                    # carries integer totals (HipOps.stats_nsum: no reduce launch, exact), else here
+                    if getattr(ops, "stats_nsum", False) and tot.dtype == torch.int64 and c.fp is None:
+                        totals = tot
+                    else:
+                        totals = tot.sum(0, keepdim=True) if c.B == 1 else tot.view(c.B, c.T, *tot.shape[1:]).sum(1)
         if per_frame:
             return ops.groupnorm(x, gb[0], gb[1], eps, c.F, silu, totals=totals)
         red = c.fp.reduce_stats if c.fp is not None else None
@@ -455,6 +463,7 @@ class UNetModel(packing.PackedWeights, nn.Module):
                 # frame shards: ONE grouped exchange carries this stage's GroupNorm partial sums and the raw boundary
                 # frames; the halo frames are normalised here, with the same global totals as this rank's own frames
                 part = tot if tot is not None else ops.groupnorm_stats(h, 1, 32)
+                part = getattr(ops, "totals_f32", lambda t_: t_)(part)  # (the exchange carries f32 {sum, sumsq})
                 tot_g, count, lo_raw, hi_raw = c.fp.exchange_stats_halo(h, P, part, h.shape[0] * (h.shape[1] // 32))
                 glob = lambda _part, _cnt: (tot_g, count)
                 t = ops.groupnorm(h, gb[0], gb[1], 1e-5, 1, True, stats_reduce=glob, totals=part)
@@ -651,6 +660,8 @@ class UNetModel(packing.PackedWeights, nn.Module):
         _unsupported(b > 1 and self.fp is not None, "batched clips in frame-sharded mode")
         c = _Ctx()
         c.ops, c.fp, c.w = self.ops, self.fp, packed
+        if hasattr(self.ops, "begin_forward"):
+            self.ops.begin_forward()  # (HipOps: one memset over this stream's GroupNorm-totals arena)
         c.B, c.T, c.F, c.H, c.W = b, t, b * t, hh, ww
         c.level = 0  # (pyramid level of the norm sites, UNetModel._site: +1 behind every Downsample, -1 behind every Upsample)
         ops = c.ops

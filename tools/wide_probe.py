@@ -23,7 +23,7 @@ args = ap.parse_args()
 
 
 def rel(a, b):
-    a, b = a.double(), b.double()
+    a, b = HipOps.totals_f32(a).double(), HipOps.totals_f32(b).double()
     return float((a - b).norm() / b.norm().clamp(min=1e-30))
 
 
