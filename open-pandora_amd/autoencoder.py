@@ -133,19 +133,19 @@ class AutoencoderKL(packing.PackedWeights, nn.Module):
         xs = x.to(device=ops.device, dtype=torch.float32).permute(1, 0, 2, 3).reshape(c, n, H * Wd).contiguous()
         pad = torch.zeros(8 - c, n, H * Wd, dtype=torch.float32, device=ops.device)
         h = ops.pack_input(xs, pad)                                   # [n*H*W, 8] (3 channels + zero pad)
-        h = self._conv(W["enc.conv_in"], h, n, H, Wd)
+        h = ops.conv3x3(h, *W["enc.conv_in"], n, H, Wd, stream=True)
         enc = self.encoder
         for lvl in range(len(enc.down)):
             for i in range(len(enc.down[lvl].block)):
                 h = self._res(W[f"enc.down.{lvl}.block.{i}"], h, n, H, Wd)
             if hasattr(enc.down[lvl], "downsample"):
-                h = self._conv(W[f"enc.down.{lvl}.downsample"], h, n, H, Wd, stride=2, pad_lo=0)
+                h = ops.conv3x3(h, *W[f"enc.down.{lvl}.downsample"], n, H, Wd, stride=2, pad_lo=0, stream=True)
                 H, Wd = H // 2, Wd // 2
         h = self._res(W["enc.mid.block_1"], h, n, H, Wd)
         h = self._attn(W["enc.mid.attn_1"], h, n, H * Wd)
         h = self._res(W["enc.mid.block_2"], h, n, H, Wd)
         h = ops.groupnorm(h, *W["enc.norm_out"], 1e-6, n, True)
-        m = self._conv(W["enc.conv_out_q"], h, n, H, Wd)  # conv_out with quant_conv folded in
+        m = ops.conv3x3(h, *W["enc.conv_out_q"], n, H, Wd, stream=True)  # conv_out with quant_conv folded in
         return ops.unpack_output(m, n, H * Wd).reshape(m.shape[1], n, H, Wd).permute(1, 0, 2, 3)
 
     def encode(self, x, **kwargs):
@@ -173,21 +173,8 @@ class AutoencoderKL(packing.PackedWeights, nn.Module):
         dev, dt = ops.device, ops.dtype
         wt = lambda t: t.detach().to(device=dev, dtype=dt).contiguous()
         f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
-        # r06: an op table in the parity configuration carries every norm output as [hi | lo]; what is left of the
-        # decoder's error is then the ONE rounding of its weights (~2.8e-4 rms relative per layer, ~30 layers).  There the weights
-        # are split too, W = round16(W) + round16(W - round16(W)), and every conv / 1x1 runs a second pass over the low part that
-        # accumulates onto the first (f32 stream output as residual): 2x the decoder's MFMA work, parity mode only.
-        split_w = bool(getattr(ops, "parity", False))
-        self._split_w = split_w
-
-        def lo(w):  # 16-bit low part of an f32 weight tensor (None outside the parity configuration)
-            if not split_w:
-                return None
-            w32 = w.detach().to(device=dev, dtype=torch.float32)
-            return (w32 - w32.to(dt).float()).to(dt).contiguous()
-
-        conv = lambda m: (wt(packing.pack_conv3x3(m.weight)), f32(m.bias), lo(packing.pack_conv3x3(m.weight)))
-        lin = lambda m: (wt(m.weight.reshape(m.weight.shape[0], -1)), f32(m.bias), lo(m.weight.reshape(m.weight.shape[0], -1)))
+        conv = lambda m: (wt(packing.pack_conv3x3(m.weight)), f32(m.bias))
+        lin = lambda m: (wt(m.weight.reshape(m.weight.shape[0], -1)), f32(m.bias))
         gn = lambda m: (f32(m.weight), f32(m.bias))
         W = {}
         for name, m in self.decoder.named_modules():
@@ -195,7 +182,7 @@ class AutoencoderKL(packing.PackedWeights, nn.Module):
                 W[name] = dict(n1=gn(m.norm1), c1=conv(m.conv1), n2=gn(m.norm2), c2=conv(m.conv2),
                                skip=lin(m.nin_shortcut) if hasattr(m, "nin_shortcut") else None)
             elif isinstance(m, _AttnBlock):
-                wv, bv = lin(m.v)[:2]
+                wv, bv = lin(m.v)
                 W[name] = dict(n=gn(m.norm), q=lin(m.q), k=lin(m.k), v=(wv, bv), o=lin(m.proj_out))
             elif isinstance(m, _Resample):
                 W[name] = conv(m.conv)
@@ -210,19 +197,19 @@ class AutoencoderKL(packing.PackedWeights, nn.Module):
         e = self.encoder
         w_in = torch.zeros(e.conv_in.weight.shape[0], 8, 3, 3)
         w_in[:, :e.conv_in.weight.shape[1]] = e.conv_in.weight.detach().float().cpu()
-        W["enc.conv_in"] = (wt(packing.pack_conv3x3(w_in)), f32(e.conv_in.bias), lo(packing.pack_conv3x3(w_in)))
+        W["enc.conv_in"] = (wt(packing.pack_conv3x3(w_in)), f32(e.conv_in.bias))
         W["enc.norm_out"] = gn(e.norm_out)
         # quant_conv (1x1) o conv_out (3x3): W' = Wq . Wc, b' = Wq . bc + bq (f64 on the host)
         wq = self.quant_conv.weight.detach().double().cpu().reshape(self.quant_conv.weight.shape[0], -1)
         wc, bc = e.conv_out.weight.detach().double().cpu(), e.conv_out.bias.detach().double().cpu()
         w_f = torch.einsum("oc,cikl->oikl", wq, wc).float()
         b_f = (wq @ bc + self.quant_conv.bias.detach().double().cpu()).float()
-        W["enc.conv_out_q"] = (wt(packing.pack_conv3x3(w_f)), f32(b_f), lo(packing.pack_conv3x3(w_f)))
+        W["enc.conv_out_q"] = (wt(packing.pack_conv3x3(w_f)), f32(b_f))
         d = self.decoder
         # conv_in reads the latent padded from z_channels to 8 channels (zero weights on the padding)
         w_in = torch.zeros(d.conv_in.weight.shape[0], 8, 3, 3)
         w_in[:, :d.conv_in.weight.shape[1]] = d.conv_in.weight.detach().float().cpu()
-        W["conv_in"] = (wt(packing.pack_conv3x3(w_in)), f32(d.conv_in.bias), lo(packing.pack_conv3x3(w_in)))
+        W["conv_in"] = (wt(packing.pack_conv3x3(w_in)), f32(d.conv_in.bias))
         W["norm_out"], W["conv_out"] = gn(d.norm_out), conv(d.conv_out)
         W["post_quant"] = (f32(self.post_quant_conv.weight.reshape(self.post_quant_conv.weight.shape[0], -1)),
                            f32(self.post_quant_conv.bias))
@@ -230,36 +217,19 @@ class AutoencoderKL(packing.PackedWeights, nn.Module):
         return self
 
     # ---- graph ----------------------------------------------------------------------------------
-    def _conv(self, w, h, F, H, Wd, residual=None, **kw):
-        """3x3 conv onto the f32 stream; w = (packed weights, bias, low part or None): the low part's pass accumulates onto
-        the first (parity configuration, see prepare)"""
-        ops = self.ops
-        y = ops.conv3x3(h, w[0], w[1], F, H, Wd, residual=residual, stream=True, **kw)
-        if w[2] is not None:
-            y = ops.conv3x3(h, w[2], None, F, H, Wd, residual=y, stream=True, **kw)
-        return y
-
-    def _lin(self, w, h, residual=None):
-        """1x1 conv / Linear onto the f32 stream, with the weights' low part as a second accumulating pass (see _conv)"""
-        ops = self.ops
-        y = ops.gemm(h, w[0], w[1], residual=residual, stream=True)
-        if w[2] is not None:
-            y = ops.gemm(h, w[2], None, residual=y, stream=True)
-        return y
-
     def _res(self, W, x, F, H, Wd):
         ops = self.ops
         h = ops.groupnorm(x, *W["n1"], 1e-6, F, True)
-        h = self._conv(W["c1"], h, F, H, Wd)
+        h = ops.conv3x3(h, *W["c1"], F, H, Wd, stream=True)
         h = ops.groupnorm(h, *W["n2"], 1e-6, F, True)
-        skip = x if W["skip"] is None else self._lin(W["skip"], x)
-        return self._conv(W["c2"], h, F, H, Wd, residual=skip)
+        skip = x if W["skip"] is None else ops.gemm(x, *W["skip"], stream=True)
+        return ops.conv3x3(h, *W["c2"], F, H, Wd, residual=skip, stream=True)
 
     def _attn(self, W, x, F, P):
         ops = self.ops
         C = x.shape[1]
         h = ops.groupnorm(x, *W["n"], 1e-6, F, False)
-        q, k = ops.gemm(h, *W["q"][:2]), ops.gemm(h, *W["k"][:2])
+        q, k = ops.gemm(h, *W["q"]), ops.gemm(h, *W["k"])
         if h.shape[1] != C:  # parity op table: the norm output is [hi | lo]; V^T below takes it as the (contiguous) W operand: hi only
             h = h[:, :C].contiguous()
         out = ops.empty(F * P, C)
@@ -269,7 +239,7 @@ class AutoencoderKL(packing.PackedWeights, nn.Module):
             pmat = ops.softmax_rows(s, C ** -0.5)
             vt = ops.gemm(W["v"][0], h[sl])                          # V^T without bias [C, P]
             ops.gemm(pmat, vt, W["v"][1], out=out[sl])               # P V + b_v (rows of P sum to 1)
-        return self._lin(W["o"], out, residual=x)
+        return ops.gemm(out, *W["o"], residual=x, stream=True)
 
     @torch.no_grad()
     def decode(self, z, scaled=False, **kwargs):
@@ -287,7 +257,7 @@ class AutoencoderKL(packing.PackedWeights, nn.Module):
         F, H, Wd = n, hh, ww
         zx = z.to(device=ops.device, dtype=torch.float32).permute(1, 0, 2, 3).reshape(c, n, hh * ww).contiguous()
         x = ops.latent_affine(zx, *W["post_quant"], (1.0 / self.scale_factor) if scaled else 1.0)
-        h = self._conv(W["conv_in"], x, F, H, Wd)
+        h = ops.conv3x3(x, *W["conv_in"], F, H, Wd, stream=True)
         h = self._res(W["mid.block_1"], h, F, H, Wd)
         h = self._attn(W["mid.attn_1"], h, F, H * Wd)
         h = self._res(W["mid.block_2"], h, F, H, Wd)
@@ -296,10 +266,10 @@ class AutoencoderKL(packing.PackedWeights, nn.Module):
             for i in range(len(up.block)):
                 h = self._res(W[f"up.{lvl}.block.{i}"], h, F, H, Wd)
             if hasattr(up, "upsample"):
-                h = self._conv(W[f"up.{lvl}.upsample"], h, F, H, Wd, upsample=True)
+                h = ops.conv3x3(h, *W[f"up.{lvl}.upsample"], F, H, Wd, upsample=True, stream=True)
                 H, Wd = 2 * H, 2 * Wd
         h = ops.groupnorm(h, *W["norm_out"], 1e-6, F, True)
-        y = self._conv(W["conv_out"], h, F, H, Wd)                           # [F*H*W, 3] f32
+        y = ops.conv3x3(h, *W["conv_out"], F, H, Wd, stream=True)           # [F*H*W, 3] f32
         return ops.unpack_output(y, F, H * Wd).reshape(3, n, H, Wd).permute(1, 0, 2, 3)
 
     @torch.no_grad()
