@@ -124,7 +124,9 @@ int pm_gemm_colstats_rows(int64_t M, int64_t N, int64_t K, int act, size_t works
  * kernel a pm_gemm call of this shape runs on, by the library's own plan - 0 = gemm_kernel (128x128 tile, two LDS
  * stages, two workgroups per CU), 1 = gemm_ring_kernel (wave-specialised 4-stage ring, one workgroup per CU),
  * 2 = gemm256_kernel (256x256 tile, 8 waves, ping-pong phases), 3 = gemm_ringw_kernel (the ring kernel on a 256x128 tile:
- * the large projections whose grids keep whole rounds at half the tile count); negative = PM_E_SHAPE.  `flags` as for pm_gemm, `workspace_bytes` the split-K scratch the call would be given. */
+ * the large projections whose grids keep whole rounds at half the tile count), 4 = gemm_wide_kernel (256x256 tile, four waves of
+ * 128x128, assembly main loop: long-K shapes in whole rounds), 5 = gemm_wide_stream_kernel (the same tile as one assembly statement,
+ * K stream continuous across tiles, assembly epilogue: the 16-bit projection / GEGLU flavours on whole 256x256 tiles); negative = PM_E_SHAPE.  `flags` as for pm_gemm, `workspace_bytes` the split-K scratch the call would be given. */
 int pm_gemm_kernel_choice(int64_t M, int64_t N, int64_t K, int act, int flags, size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------------------------------

@@ -29,6 +29,9 @@ void pm_debug_attn_stamps(void* buf);
 /* Kernel choice of pm_gemm for the 256x256 assembly-loop kernel (csrc/gemm_wide.hip): 0 = never, 1 = by its rule (initial value,
  * unless PANDORA_GEMM_WIDE is set), 2 = wherever it is legal.  Process-wide: measurement runs and the forced-kernel parity tests. */
 void pm_debug_gemm_wide(int mode);  /* (+ 16 x loop variant of tools/gen_wide_loop.py VARIANTS: timing-only ablations, 7 = stamps) */
+/* The same switch for gemm_wide_stream (csrc/gemm_wide_stream.hip: the tile of gemm_wide as one assembly statement per workgroup, K
+ * stream continuous across tiles): 0 = never, 1 = by its rule (initial value unless PANDORA_GEMM_WSTREAM is set), 2 = wherever legal. */
+void pm_debug_gemm_wstream(int mode);
 /* In-kernel stamps of gemm_wide's loop variant 7: per workgroup b, buf[8 b + 0..6] = shader cycles in the tile prologues / K loops /
  * epilogues, -, K-steps walked, end-of-kernel s_memtime and s_memrealtime.  `buf`: device memory of 64 bytes x grid size; NULL = off. */
 void pm_debug_wide_stamps(void* buf);

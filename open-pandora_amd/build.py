@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpandora_mi355x.so")
 LIB_DIAG = os.path.join(HERE, "libpandora_mi355x_diag.so")
 STAMP = LIB + ".stamp"
-SOURCES = ["gemm.hip", "gemm_wide.hip", "gemm256.hip", "lngemm.hip", "attn.hip", "attn16.hip", "norm.hip", "misc.hip", "peer.hip"]
+SOURCES = ["gemm.hip", "gemm_wide.hip", "gemm_wide_stream.hip", "gemm256.hip", "lngemm.hip", "attn.hip", "attn16.hip", "norm.hip", "misc.hip", "peer.hip"]
 HEADERS = ["common.hpp", "gemm_common.hpp", "gemm_wide_loop.inc", "attn_common.hpp", os.path.join("..", "..", "include", "pandora_mi355x.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 LDFLAGS = ["--offload-arch=gfx950", "-fPIC", "-shared"]

@@ -94,6 +94,7 @@ DIAG_SIGNATURES = {
     "pm_debug_attn_variant": (None, [c_int]),
     "pm_debug_attn_stamps": (None, [c_void_p]),
     "pm_debug_gemm_wide": (None, [c_int]),
+    "pm_debug_gemm_wstream": (None, [c_int]),
     "pm_debug_wide_stamps": (None, [c_void_p]),
     "pm_debug_erf": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
 }

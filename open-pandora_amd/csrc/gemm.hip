@@ -1617,6 +1617,9 @@ extern "C" int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, c
   if (K % BK) return PM_E_SHAPE;  // all Linear layers on the path have K % 64 == 0
   plan_split(p, workspace, workspace_bytes);
   if (p.colstats != nullptr && p.splits > 1 && ((p.ldc & 3) || (p.R != nullptr && (p.ldr & 3)))) return PM_E_SHAPE;
+  // the 16-bit projection flavours on whole 256 x 256 tiles: the assembly kernel with the K stream continuous across tiles
+  if (gemm_wide_stream_wanted(p, flags, num_cus()))
+    PM_DISPATCH_DTYPE(dtype, T, return (launch_gemm_wide_stream<T>(p, num_cus(), (hipStream_t)stream)));
   // wide / long-K shapes whose grid keeps whole rounds of 256 x 256 tiles: four waves of 128 x 128, assembly main loop (gemm_wide.hip)
   if (gemm_wide_wanted(p, flags, num_cus())) PM_DISPATCH_DTYPE(dtype, T, return (launch_gemm_wide<T>(p, num_cus(), (hipStream_t)stream)));
   // large MFMA-bound shapes: 256x256 tiles, 8-phase ping-pong (gemm256.hip) - where the 256x128 ring kernel is not preferred
@@ -1740,6 +1743,10 @@ extern "C" int pm_gemm_kernel_choice(int64_t M, int64_t N, int64_t K, int act, i
   p.ntiles = (int)((N + BN - 1) / BN);
   static float dummy_ws;  // (only its non-NULLness matters to plan_split)
   plan_split(p, workspace_bytes ? &dummy_ws : nullptr, workspace_bytes);
+  // (dense 16-bit call of contiguous operands, no residual / statistics / f32 output: what the caller of this query describes)
+  p.lda = K; p.ldw = K; p.ldc = act == PM_ACT_GEGLU ? N / 2 : N;
+  if (gemm_wide_stream_wanted(p, flags, num_cus())) return 5;  // gemm_wide_stream (r06)
+  if (gemm_wide_wanted(p, flags, num_cus())) return 4;         // gemm_wide (r06)
   if (p.splits == 1 && ((g_ringw == 2 && g_ring == 2) || (g_ringw == 1 && g_ring != 0 && prefer_ringw(A_DENSE, p))))
     return 3;  // the 256x128 ring kernel (launch<T, A_DENSE>'s first choice)
   if (!(g_ringw == 2 && g_ring == 2) && gemm256_wanted(p, flags, num_cus())) return 2;

@@ -647,4 +647,8 @@ template <typename T> int launch_gemm256(const GemmParams& p, int num_cus, hipSt
 bool gemm_wide_wanted(const GemmParams& p, int flags, int num_cus);
 template <typename T> int launch_gemm_wide(const GemmParams& p, int num_cus, hipStream_t stream);
 
+// gemm_wide_stream.hip: the same tile as ONE assembly statement per workgroup (continuous K stream, assembly epilogue; r06)
+bool gemm_wide_stream_wanted(const GemmParams& p, int flags, int num_cus);
+template <typename T> int launch_gemm_wide_stream(const GemmParams& p, int num_cus, hipStream_t stream);
+
 }  // namespace pm

@@ -55,6 +55,7 @@ class HipOps:
             self.q_prescale = None
         # LayerNorm + projection pairs of the shallow levels as ONE kernel (pm_ln_gemm); "0": the two-kernel pair (A/B)
         self.fused_ln = os.environ.get("PANDORA_FUSED_LN", "1") != "0"
+        self.ln_pair_stream = os.environ.get("PANDORA_LN_PAIR_STREAM", "1") != "0"
         # f32 operands (the residual stream into skip 1x1 convs, Downsample / Upsample convs) are rounded by one
         # pm_split16 pass and run on the DMA-staged 16-bit kernels; "0": the register-staged f32 loaders (A/B)
         self.presplit = os.environ.get("PANDORA_PRESPLIT", "1") != "0"
@@ -453,8 +454,13 @@ class HipOps:
         M, K = x.shape
         N = w.shape[0]
         code = capi.ACT_CODES[act]
-        if (self.fused_ln and not self._hilo() and x.dtype == torch.float32 and code in (capi.PM_ACT_NONE, capi.PM_ACT_GEGLU)
-                and self.lib.pm_ln_gemm_supported(M, N, K, code)):
+        # r06: where the projection itself would run on gemm_wide_stream (GEGLU / plain 16-bit flavours on whole 256 x 256 tiles: 25-
+        # 33 % ahead of the other GEMM kernels at K = 320), the pm_layernorm + pm_gemm pair beats the panel kernel
+        # (profiles/r06/wide_stream_probe.txt); PANDORA_LN_PAIR_STREAM=0 keeps the panel kernel (A/B)
+        stream_pair = (self.ln_pair_stream and col_scale is None and code in (capi.PM_ACT_NONE, capi.PM_ACT_GEGLU)
+                       and self.lib.pm_gemm_kernel_choice(M, N, K, code, 0, self.ws_bytes) == 5)
+        if (self.fused_ln and not stream_pair and not self._hilo() and x.dtype == torch.float32
+                and code in (capi.PM_ACT_NONE, capi.PM_ACT_GEGLU) and self.lib.pm_ln_gemm_supported(M, N, K, code)):
             assert w.shape[1] == K and w.is_contiguous() and w.dtype == self.dtype and x.stride(1) == 1
             flags = 0
             if col_scale is not None:

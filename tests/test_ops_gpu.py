@@ -323,6 +323,47 @@ def test_gemm_wide_256x256_asm_loop(hip_ops_factory, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_wide_stream_one_statement_kernel(hip_ops_factory, dtype):
+    """gemm_wide_stream_kernel (csrc/gemm_wide_stream.hip, r06: the 256x256 tile as ONE generated assembly statement per
+    workgroup - K stream continuous across tiles, bias as the accumulators' initial value, conversion + stores in assembly),
+    forced through the diagnostics build on whole-tile shapes: exact-integer products must equal the other kernels BIT FOR BIT
+    (K loops of 4, 5, 7 and 20 steps: both parities of the two-buffer loop, tiles per workgroup 1 .. 4: the cross-tile stream with
+    odd K-step counts flips the buffer parity between tiles), + bias and GEGLU against the f32 reference, and the library's own
+    rule sends the model's GEGLU projections there (pm_gemm_kernel_choice == 5)."""
+    ops = hip_ops_factory(dtype, diag=True)
+    g = torch.Generator().manual_seed(9)
+    try:
+        for M, N, K in [(256, 256, 256), (512, 768, 320), (8192, 8192, 448), (1024, 1024, 1280)]:
+            a = torch.randint(-3, 4, (M, K), generator=g).to(dtype).cuda()
+            w = torch.randint(-3, 4, (N, K), generator=g).to(dtype)
+            w[:, 1::3] *= 0
+            w = w.cuda()
+            outs = []
+            for mode in (0, 2):
+                ops.lib.pm_debug_gemm_wide(0)
+                ops.lib.pm_debug_gemm_wstream(mode)
+                outs.append(ops.gemm(a, w).float())
+            assert torch.equal(outs[0], outs[1]), (M, N, K)
+            assert torch.equal(outs[1][:64, :64].cpu(), (a[:64].float().cpu() @ w[:64].float().cpu().t()).to(dtype).float())
+        M, N, K = 2048, 1536, 640
+        a, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=2)
+        bias = rnd(N, dtype=torch.float32, seed=3)
+        da, dw, db = dev(a, w, bias)
+        wgp, bgp = packing.pack_geglu(w, bias)
+        ops.lib.pm_debug_gemm_wstream(2)
+        assert rel_err(ops.gemm(da, dw, db), REF.gemm(a, w, bias, None, "none")) <= TOL[dtype]
+        assert rel_err(ops.gemm(da, wgp.cuda(), bgp.cuda(), act="geglu"), _geglu_ref(a, w, bias)) <= TOL[dtype]
+        ops.lib.pm_debug_gemm_wstream(1)
+        ops.lib.pm_debug_gemm_wide(1)
+        for shape in ((10240, 5120, 640), (2560, 10240, 1280), (40960, 2560, 320), (36864, 5120, 640)):
+            assert ops.lib.pm_gemm_kernel_choice(*shape, 2, 0, ops.ws_bytes) == 5, shape  # GEGLU projections of both resolutions
+        assert ops.lib.pm_gemm_kernel_choice(2560, 1280, 5120, 0, 0, ops.ws_bytes) != 5      # 50 tiles: split-K stays
+    finally:
+        ops.lib.pm_debug_gemm_wstream(1)
+        ops.lib.pm_debug_gemm_wide(1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_ringw_256x128_tiles(hip_ops_factory, dtype):
     """gemm_ringw_kernel (the ring kernel on 256x128 tiles, csrc/gemm.hip), selected by the library's own rule
     (pm_gemm_kernel_choice == 3: unsplit, K >= 512, whole rounds of 256-row tiles): exact-integer product with a ragged last

@@ -17,6 +17,7 @@ ap.add_argument("--quick", action="store_true")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--skip-check", action="store_true")
+ap.add_argument("--stream", action="store_true", help="gemm_wide_stream: parity + timing against the other kernels and the vendor library")
 ap.add_argument("--stamps", action="store_true", help="in-kernel stamps of loop variant 7 (prologue / loop / epilogue cycles, clock)")
 ap.add_argument("--variants", default="", help="comma list of loop variants (diagnostics build) timed on the first shapes")
 args = ap.parse_args()
@@ -114,6 +115,68 @@ def timing():
     ops.lib.pm_debug_gemm_wide(1)
 
 
+def stream():
+    """gemm_wide_stream forced (pm_debug_gemm_wstream(2)) against the other kernels (both assembly kernels off) on whole-tile shapes"""
+    bad = 0
+    for dtype in (torch.bfloat16, torch.float16):
+        ops = HipOps(dtype, "cuda:0", diag=True)
+        g = torch.Generator(device="cuda").manual_seed(3)
+        rn = lambda *s, dt=dtype, sc=1.0: (torch.randn(*s, device="cuda", generator=g) * sc).to(dt)
+        for (M, N, K) in [(256, 256, 256), (512, 768, 320), (1024, 512, 640), (2048, 2048, 1280), (8192, 8192, 448), (36864, 5120, 640)]:
+            a, w = rn(M, K), rn(N, K, sc=K ** -0.5)
+            bias = rn(N, dt=torch.float32)
+            wp, bp = packing.pack_geglu(w.cpu(), bias.cpu())
+            want = a.float() @ w.float().t()
+            xv, gate = (want + bias).chunk(2, dim=-1)
+            cases = [("plain", w, dict(), want), ("bias", w, dict(bias=bias), want + bias),
+                     ("geglu", wp.cuda(), dict(bias=bp.cuda(), act="geglu"), xv * torch.nn.functional.gelu(gate))]
+            for name, ww, kw, ref in cases:
+                outs = {}
+                for mode in (0, 2):
+                    ops.lib.pm_debug_gemm_wide(0)
+                    ops.lib.pm_debug_gemm_wstream(mode)
+                    outs[mode] = ops.gemm(a, ww, **kw).float()
+                    torch.cuda.synchronize()
+                same = torch.equal(outs[0], outs[2])
+                e0, e2 = rel(outs[0], ref), rel(outs[2], ref)
+                # plain: the same MFMA chain in the same order -> bit-equal; bias / GEGLU: the bias is the accumulators' INITIAL value
+                # here (added first, not last): equal to f32 rounding order, judged against the f32 reference
+                ok = same if name == "plain" else e2 <= 1.05 * e0 + 1e-6
+                bad += 0 if ok else 1
+                print(f"[stream check {str(dtype)[6:]}] M={M} N={N} K={K} {name:6s} vs f32 reference: other {e0:.3e} stream {e2:.3e} bit-equal {same}"
+                      + ("" if ok else "   <-- MISMATCH"), flush=True)
+    print(f"# stream mismatches: {bad}")
+    ops = HipOps(torch.bfloat16, "cuda:0", diag=True)
+    shapes = [(8192, 8192, 8192, "none"), (9216, 10240, 1280, "geglu"), (36864, 5120, 640, "geglu"), (147456, 2560, 320, "geglu"),
+              (10240, 5120, 640, "geglu"), (2560, 10240, 1280, "geglu"), (40960, 2560, 320, "geglu"), (640, 10240, 1280, "geglu"),
+              (9216, 3840, 1280, "none"), (2560, 3840, 1280, "none"), (9216, 1280, 5120, "none"), (2560, 1280, 5120, "none"),
+              (2560, 1280, 1280, "none"), (10240, 768, 640, "none"), (36864, 1280, 2560, "none"), (4096, 4096, 4096, "none"),
+              (40960, 512, 512, "none"), (2304, 10240, 1280, "geglu")]
+    if args.quick:
+        shapes = shapes[:4]
+    for M, N, K, act in shapes:
+        a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+        w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16) * K ** -0.5
+        bias = torch.randn(N, device="cuda", dtype=torch.float32)
+        out = torch.empty(M, N // 2 if act == "geglu" else N, device="cuda", dtype=torch.bfloat16)
+        full = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        wt = w.t()
+        t = {"other": [], "wide": [], "stream": [], "lib": []}
+        for _ in range(args.rounds):
+            for name, wd, ws in (("other", 0, 0), ("wide", 2, 0), ("stream", 0, 2)):
+                ops.lib.pm_debug_gemm_wide(wd)
+                ops.lib.pm_debug_gemm_wstream(ws)
+                t[name].append(bench(lambda: ops.gemm(a, w, bias, act=act, out=out), args.reps))
+            t["lib"].append(bench(lambda: torch.matmul(a, wt, out=full), args.reps))  # (plain product: the library fuses no GEGLU)
+        fl = 2.0 * M * N * K
+        m = {k: min(v) for k, v in t.items()}
+        print(f"M={M:6d} N={N:5d} K={K:5d} {act:5s}: " + " | ".join(f"{k} {m[k]:7.1f} us {fl / m[k] / 1e6:5.0f}" for k in ("other", "wide", "stream", "lib"))
+              + f" | stream/other {m['stream'] / m['other']:4.2f} stream/lib(plain) {m['stream'] / m['lib']:4.2f}", flush=True)
+    ops.lib.pm_debug_gemm_wide(1)
+    ops.lib.pm_debug_gemm_wstream(1)
+    return bad
+
+
 def variants():
     ops = HipOps(torch.bfloat16, "cuda:0", diag=True)
     vs = [int(v) for v in args.variants.split(",")]
@@ -169,6 +232,8 @@ def stamps():
 
 
 if __name__ == "__main__":
+    if args.stream:
+        sys.exit(1 if stream() else 0)
     if args.stamps:
         stamps()
         sys.exit(0)
