@@ -33,12 +33,15 @@ def dynamic_resize(img):
     w, h = img.size
     nw, nh = (576, int(576 * h / w)) if w <= h else (int(576 * w / h), 576)
     img = img.resize((nw, nh), Image.BILINEAR)
-    left, top = int(round((nw - 1024) / 2.0)), int(round((nh - 576) / 2.0))
-    if left < 0 or top < 0:  # (CenterCrop pads with zeros when the image is smaller than the crop)
+    if nw < 1024 or nh < 576:
+        # torchvision's CenterCrop pads a smaller image with zeros FIRST: (crop - size) // 2 on the left / top, the rest on the
+        # right / bottom (functional.center_crop) - not round((size - crop) / 2) of the negative offset (one pixel off
+        # when the deficit is 3 mod 4)
+        pl, pt = max(0, (1024 - nw) // 2), max(0, (576 - nh) // 2)
         canvas = Image.new(img.mode, (max(nw, 1024), max(nh, 576)))
-        canvas.paste(img, (max(0, -left), max(0, -top)))
+        canvas.paste(img, (pl, pt))
         img, (nw, nh) = canvas, canvas.size
-        left, top = int(round((nw - 1024) / 2.0)), int(round((nh - 576) / 2.0))
+    left, top = int(round((nw - 1024) / 2.0)), int(round((nh - 576) / 2.0))
     return img.crop((left, top, left + 1024, top + 576))
 
 
@@ -82,13 +85,31 @@ class WorldModel:
         (LatentVisualDiffusion.forward -> p_losses; the U-Net takes its differentiable walk).  -> loss; the dictionary the
         reference hands to `log_dict` is kept as `self.last_loss_dict`."""
         del batch_idx
+        # (ADVICE r05: factory.build_diffusion hands the U-Net out in eval(); its forward then takes the no_grad kernel path and
+        # the loss has no grad_fn - say so here instead of failing inside autograd)
+        unet = self.diffusion_model.model.diffusion_model
+        if not unet.training:
+            raise RuntimeError("WorldModel.training_step: the diffusion U-Net is in eval() - call .train() on it (WorldModel.train()) "
+                               "first; in eval mode its forward runs the forward-only HIP kernels")
         x, c, fs = self.get_batch_input(**batch, random_uncond=False)
         loss, self.last_loss_dict = self.diffusion_model(x, c, fs=fs.long())
+        if not loss.requires_grad:
+            raise RuntimeError("WorldModel.training_step: the loss carries no gradient (autograd disabled, or no parameter requires grad)")
         return loss
+
+    def train(self, mode=True):
+        """nn.Module-style switch forwarded to the diffusion model (the shell itself is a plain object)"""
+        self.diffusion_model.train(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
 
     def configure_optimizers(self):
         """model.py:951-974 (`do_alignment` False): AdamW over `diffusion_model.model.parameters()` (the DiffusionWrapper = the
         U-Net's 1516 tensors) plus the LLM-side bridge parameters handed in as `self.extra_trainable`; lr from `config`."""
+        if getattr(self, "config", None) is None or not hasattr(self.config, "learning_rate"):
+            raise ValueError("WorldModel.configure_optimizers: `config.learning_rate` is required (model.py:951-974 reads it)")
         params = list(self.diffusion_model.model.parameters()) + list(getattr(self, "extra_trainable", []))
         return torch.optim.AdamW(params, lr=self.config.learning_rate)
 

@@ -646,7 +646,13 @@ class UNetModel(packing.PackedWeights, nn.Module):
             from . import unet_train
             return unet_train.forward(self, x, timesteps, context, fs, features_adapter)
         with torch.no_grad():
-            return self._forward(x, timesteps, context, features_adapter, fs, **kwargs)
+            try:
+                return self._forward(x, timesteps, context, features_adapter, fs, **kwargs)
+            finally:
+                # (a forward that raises must not leave its last site on the shared op table - first-stage /
+                # Resampler calls on the same HipOps would silently take a U-Net site's [hi | lo] decision)
+                if self.ops is not None and hasattr(self.ops, "site"):
+                    self.ops.site = None
 
     def _forward(self, x, timesteps, context=None, features_adapter=None, fs=None, **kwargs):
         if self.ops is None:
@@ -691,7 +697,14 @@ class UNetModel(packing.PackedWeights, nn.Module):
         # stream capture (the sampler's own batched call: t = cat([t, t]), validated on its warm-up forward).
         if b > 1:
             for name, v in (("timestep", timesteps), ("fs", fs)):
+                # (a device tensor costs a blocking read-back per eager forward: checked on the FIRST forward of a
+                # batch size only - the sampler's warm-up forward - host tensors every time)
                 if torch.is_tensor(v) and v.numel() > 1 and not (v.is_cuda and torch.cuda.is_current_stream_capturing()):
+                    if v.is_cuda:
+                        seen = self.__dict__.setdefault("_batched_checked", set())
+                        if (name, b) in seen:
+                            continue
+                        seen.add((name, b))
                     if not bool((v == v.reshape(-1)[0]).all()):
                         raise NotImplementedError(f"batched clips share one {name} (the CFG pair of a DDIM step)")
         c.emb_bias = self._embed(c, timesteps, fs)

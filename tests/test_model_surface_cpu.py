@@ -71,6 +71,13 @@ def test_dynamic_resize_is_resize_576_then_center_crop():
     assert M.dynamic_resize(tall).size == (1024, 576)
     exact = Image.fromarray(np.arange(576 * 1024 * 3, dtype=np.uint32).astype(np.uint8).reshape(576, 1024, 3))
     assert np.array_equal(np.asarray(M.dynamic_resize(exact)), np.asarray(exact))
+    # a narrow image whose deficit is 3 mod 4 (576 x 1021 after the resize): torchvision's CenterCrop pads
+    # (1024 - 1021) // 2 = 1 column on the left and 2 on the right - not round(3 / 2) = 2 on the left.  Hand-computed case:
+    # a 576 x 1021 image of ones (no resampling: the shorter side IS 576) must land in columns 1 .. 1021 of a zero canvas.
+    ones = Image.fromarray(np.full((576, 1021, 3), 255, np.uint8))
+    got = np.asarray(M.dynamic_resize(ones))
+    assert got.shape == (576, 1024, 3)
+    assert (got[:, 0] == 0).all() and (got[:, 1:1022] == 255).all() and (got[:, 1022:] == 0).all()
 
 
 def test_world_model_generate_signature_and_asserts():
