@@ -39,7 +39,7 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16, MI355X_MICROARCH.md
 T = 16
 
 KERNELS = {
-    "gemm": "pm_gemm + pm_ln_gemm (dense nn.Linear / 1x1: gemm_kernel<A_DENSE> 2-stage, gemm_ring_kernel<A_DENSE>, gemm_ringw_kernel<A_DENSE> 256x128, split-K reduce; ln_gemm_kernel = LayerNorm + projection at K = 320)",
+    "gemm": "pm_gemm + pm_ln_gemm (dense nn.Linear / 1x1: gemm_kernel<A_DENSE> 2-stage, gemm_ring_kernel<A_DENSE>, gemm_ringw_kernel<A_DENSE> 256x128, split-K reduce; ln_gemm_kernel = LayerNorm + projection at K = 320; r06: gemm_wide_stream_kernel = 256x256 tile as one assembly statement on the GEGLU / wide 16-bit projections, gemm_wide_kernel)",
     "conv3x3": "pm_conv2d_3x3 (gemm_ring_kernel<A_CONV3X3_FAST>; gemm_kernel for f32-operand / strided / upsampling convs)",
     "conv_t3": "pm_conv_temporal_k3 (gemm_kernel / gemm_ring_kernel<A_CONVT3>)",
     "attention": "pm_attention (attn_self_kernel: spatial self-attention; attn_kernel: text+image cross-attention)",
@@ -338,7 +338,7 @@ def committed_traffic(res, fam="gemm"):
     """HBM-side bytes per launch of a kernel family from the committed PMC summary (separate rocprofv3 --pmc passes over
     one eager forward, gfx950 FETCH_SIZE correction applied there: tools/pmc_traffic.py) - only when it was taken with
     the library sources of THIS run; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r05", "pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r06", "pmc_traffic.json")
     try:
         from open_pandora_amd import build as _b
         with open(path) as f:

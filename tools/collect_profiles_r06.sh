@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-5 measurement artefacts on the GPU box -> $OUT_ROOT/r05 (copy what is to be judged into profiles/r05 afterwards).
-# usage: tools/collect_profiles_r05.sh [a|b|c|all]   a = bench + kernel stats + per-forward tables; b = SQ counters of the
+# Round-6 measurement artefacts on the GPU box -> $OUT_ROOT/r06 (copy what is to be judged into profiles/r06 afterwards).
+# usage: tools/collect_profiles_r06.sh [a|b|c|all]   a = bench + kernel stats + per-forward tables; b = SQ counters of the
 # attention shapes; c = HBM-side traffic per launch (FETCH_SIZE / WRITE_SIZE passes of their own) -> pmc_traffic.json
 set -u
-PART=${1:-all}; O=${OUT_ROOT:-gpurun_out}/r05; mkdir -p $O
+PART=${1:-all}; O=${OUT_ROOT:-gpurun_out}/r06; mkdir -p $O
 export TMPDIR=/tmp
 PMC_SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
 INC="--kernel-include-regex pm"

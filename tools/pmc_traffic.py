@@ -19,7 +19,7 @@ from open_pandora_amd import build  # noqa: E402
 def family(name):
     """kernel name -> family of bench.py's roofline.families (mangled or demangled spelling)"""
     m = re.search(r"gemm_(?:ringw?_)?kernelI\w+?Li(\d)E", name) or re.search(r"gemm_(?:ringw?_)?kernel<[^,]+, (\d)", name)
-    if "ln_gemm_kernel" in name or "gemm256_kernel" in name:
+    if "ln_gemm_kernel" in name or "gemm256_kernel" in name or "gemm_wide" in name:
         return "gemm"
     if m:
         return {"0": "gemm", "1": "conv3x3", "3": "conv3x3", "2": "conv_t3"}[m.group(1)]
