@@ -26,7 +26,8 @@ AO, BO = 48, 56          # v48.. A row offsets, v56.. W row offsets
 T0, BIAS = 128, 160      # epilogue temporaries / next tile's bias (fragment set 1)
 TA, TW, TC, TB, TAN, TWN, TCN, TBN, TIDX, PAR, STMP2 = ("s%d" % r for r in range(70, 81))
 KW, KA, NCNT, STMP, SROW = "s90", "s91", "s92", "s93", "s94"
-GC = ["s95", "s96", "s97", "s98", "s99"]  # gelu_q_exp2's coefficients c4..c0 (c5 is a v_mov literal): VOP3 takes no literal on gfx9
+GC = ["s82", "s84", "s86", "s88", "s96"]  # gelu_q_exp2's coefficients c4..c0, each the low half of an aligned pair (VOP3P source;
+#                                          op_sel_hi = 0 broadcasts it); c5 sits in a VGPR pair: VOP3 takes no literal on gfx9
 
 
 class E2(Emit):
@@ -144,33 +145,43 @@ def bias_reg(j8, r, geglu):
     return BIAS + (pj * 2 + (j >> 1)) * 8 + (j & 1) * 4 + r
 
 
-def acc_init(e, geglu):
+def acc_init_rows(e, geglu, rbs):
+    """accumulators of row blocks `rbs` <- the NEXT tile's bias (v160..v191)"""
     for k in range(8):
         e.need_loaded(100 + k)
-    for i8 in range(8):
+    for i8 in rbs:
         for j8 in range(8):
             for r in range(4):
                 e.ins(f"v_accvgpr_write_b32 a{acc(i8, j8) + r}, v{bias_reg(j8, r, geglu)}")
+
+
+def acc_init(e, geglu):
+    acc_init_rows(e, geglu, range(8))
     e.ins("s_nop 4")
 
 
 GELU_C = ["0xba05bb0c", "0x3bf0996a", "0xbd56e399", "0xbeeb2c8f", "0xbf93565f", "0xbf800009"]  # gelu_q_exp2 c5..c0 (common.hpp), f32 bits
-SCR = 152  # v152..v155: polynomial scratch of the GEGLU epilogue (the rotating conversion groups are v128..v151)
+TT, QQ, C5 = 144, 148, 152  # GEGLU epilogue scratch: |g| (4), polynomial (4), the pair (c5, c5); conversion groups rotate over v128..v143
 
 
 def epilogue(e, geglu, cvt):
     """accumulators -> 16-bit output.  lin: 8 adjacent columns per (row block, block pair): 4 cvt_pk + one 16-byte store;
-    geglu: (value) * gelu(gate), 4 columns per pair: 2 cvt_pk + one 8-byte store.  Temporaries rotate over three groups of 8
-    (a store's data registers are not rewritten for two groups: the store reads them late)."""
+    geglu: (value) * gelu(gate), 4 columns per pair: packed-f32 arithmetic (two elements per instruction: no MFMA runs beside
+    it here), 2 cvt_pk + one 8-byte store.  A row block's accumulators are re-initialised (the next tile's bias) right behind
+    its last read, between the stores.  Temporaries rotate over groups of 8 (a store reads its data registers late)."""
     e.ins("s_nop 7")
     e.ins("s_nop 7")
     bias_loads(e, TBN, geglu)
     e.ins(f"s_mov_b32 {SROW}, {TC}")
+    if geglu:
+        e.ins(f"v_mov_b32 v{C5}, {GELU_C[0]}")
+        e.ins(f"v_mov_b32 v{C5 + 1}, {GELU_C[0]}")
+    ngrp = 2 if geglu else 3
     grp = 0
     for rb in range(8):            # row block of the wave's 128 rows
         for pj in range(2):
             for jp in range(2):
-                t = T0 + 8 * (grp % 3)
+                t = T0 + 8 * (grp % ngrp)
                 grp += 1
                 j0 = pj * 4 + 2 * jp
                 for r in range(4):
@@ -187,25 +198,25 @@ def epilogue(e, geglu, cvt):
                             e.ins(f"v_pack_b32_f16 v{t + k}, v{t + 2 * k}, v{t + 2 * k + 1}")
                     e.vm_store(f"buffer_store_dwordx4 {vr(t)}, %[cvo], %[cdesc], {SROW} offen offset:{(pj * 64 + jp * 32) * 2}")
                 else:
-                    # gate g = v[t+4+r]: gelu(g) = h + |h| - |g| 2^P(|g|), h = g / 2 (common.hpp gelu_erf_f); value v[t+r].
-                    # the four elements interleaved: no instruction reads a transcendental's result right behind it
+                    # value v[t..t+3], gate g = v[t+4..t+7]; T = |g|; gelu(g) = 0.5 (g + T) - T 2^P(T)  (common.hpp gelu_erf_f)
+                    g = t + 4
                     for r in range(4):
-                        e.ins(f"v_mov_b32 v{SCR + r}, {GELU_C[0]}")
-                    for cst in GC:
-                        for r in range(4):
-                            e.ins(f"v_fma_f32 v{SCR + r}, v{SCR + r}, |v{t + 4 + r}|, {cst}")
+                        e.ins(f"v_and_b32 v{TT + r}, 0x7fffffff, v{g + r}")
+                    for h in (0, 2):
+                        e.ins(f"v_pk_fma_f32 {vr(QQ + h, 2)}, {vr(TT + h, 2)}, {vr(C5, 2)}, s[{GC[0][1:]}:{int(GC[0][1:]) + 1}] op_sel_hi:[1,1,0]")
+                    for cst in GC[1:]:
+                        for h in (0, 2):
+                            e.ins(f"v_pk_fma_f32 {vr(QQ + h, 2)}, {vr(QQ + h, 2)}, {vr(TT + h, 2)}, s[{cst[1:]}:{int(cst[1:]) + 1}] op_sel_hi:[1,1,0]")
                     for r in range(4):
-                        e.ins(f"v_exp_f32 v{SCR + r}, v{SCR + r}")
-                    for r in range(4):
-                        e.ins(f"v_mul_f32 v{SCR + r}, v{SCR + r}, |v{t + 4 + r}|")   # |g| Q(|g|)
-                    for r in range(4):
-                        e.ins(f"v_mul_f32 v{t + 4 + r}, 0.5, v{t + 4 + r}")          # h
-                    for r in range(4):
-                        e.ins(f"v_add_f32 v{t + 4 + r}, v{t + 4 + r}, |v{t + 4 + r}|")  # h + |h|
-                    for r in range(4):
-                        e.ins(f"v_sub_f32 v{t + 4 + r}, v{t + 4 + r}, v{SCR + r}")      # gelu(g)
-                    for r in range(4):
-                        e.ins(f"v_mul_f32 v{t + r}, v{t + r}, v{t + 4 + r}")
+                        e.ins(f"v_exp_f32 v{QQ + r}, v{QQ + r}")
+                    for h in (0, 2):
+                        e.ins(f"v_pk_add_f32 {vr(g + h, 2)}, {vr(g + h, 2)}, {vr(TT + h, 2)}")       # g + |g|
+                    for h in (0, 2):
+                        e.ins(f"v_pk_mul_f32 {vr(QQ + h, 2)}, {vr(QQ + h, 2)}, {vr(TT + h, 2)}")     # |g| Q(|g|)
+                    for h in (0, 2):
+                        e.ins(f"v_pk_fma_f32 {vr(g + h, 2)}, {vr(g + h, 2)}, 0.5, {vr(QQ + h, 2)} op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]")
+                    for h in (0, 2):
+                        e.ins(f"v_pk_mul_f32 {vr(t + h, 2)}, {vr(t + h, 2)}, {vr(g + h, 2)}")
                     if cvt == "bf16":
                         e.ins(f"v_cvt_pk_bf16_f32 v{t}, v{t}, v{t + 1}")
                         e.ins(f"v_cvt_pk_bf16_f32 v{t + 1}, v{t + 2}, v{t + 3}")
@@ -215,9 +226,10 @@ def epilogue(e, geglu, cvt):
                         e.ins(f"v_pack_b32_f16 v{t}, v{t}, v{t + 1}")
                         e.ins(f"v_pack_b32_f16 v{t + 1}, v{t + 2}, v{t + 3}")
                     e.vm_store(f"buffer_store_dwordx2 {vr(t, 2)}, %[cvo], %[cdesc], {SROW} offen offset:{(pj * 32 + jp * 16) * 2}")
+        acc_init_rows(e, geglu, [rb])
         if rb < 7:
             e.ins(f"s_add_u32 {SROW}, {SROW}, %[rs]")
-    acc_init(e, geglu)
+    e.ins("s_nop 4")
 
 
 def next_scalars(e):
@@ -247,6 +259,7 @@ def prologue(e, geglu):
     if geglu:
         for cst, sg in zip(GELU_C[1:], GC):
             e.ins(f"s_mov_b32 {sg}, {cst}")
+            e.ins(f"s_mov_b32 s{int(sg[1:]) + 1}, {cst}")
     e.ins("v_mov_b32 v128, %[tbl]")
     e.lds_op("ds_read_b128 v[132:135], v128", writes=range(132, 136))
     e.drain_lds()
