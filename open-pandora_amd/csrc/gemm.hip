@@ -363,6 +363,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     // 64 x 64 piece lies inside the matrix: gemm_common.hpp epilogue_lean16)
     if (AMODE == A_DENSE && !res_done && epilogue_lean16_ok(p, m0 + wm * 64, n0 + wn * 64))
       epilogue_lean16<T>(p, acc, bv, m0 + wm * 64, n0 + wn * 64, fr, fq);
+    else if (epilogue_lean32_ok(p, m0 + wm * 64, n0 + wn * 64, res_done))  // (the all-f32 flavours of every A mode)
+      epilogue_lean32<T>(p, acc, bv, m0 + wm * 64, n0 + wn * 64, fr, fq, mt * WMW + wm, split);
     else
       epilogue_regs<T>(p, acc, bv, m0, n0, wm, wn, fr, fq, mt * WMW + wm, split, res_done);
     if (!has_next) break;
@@ -751,6 +753,8 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
     // ---------------- epilogue of this wave's 64x64 quadrant (the loaders keep streaming the next tile) ----
     if (AMODE == A_DENSE && !res_done && epilogue_lean16_ok(p, m0 + wm * 64, n0 + wn * 64))
       epilogue_lean16<T>(p, acc, bv, m0 + wm * 64, n0 + wn * 64, fr, fq);  // (r06: see gemm_kernel)
+    else if (epilogue_lean32_ok(p, m0 + wm * 64, n0 + wn * 64, res_done))
+      epilogue_lean32<T>(p, acc, bv, m0 + wm * 64, n0 + wn * 64, fr, fq, mt * 2 + wm, split);
     else
       epilogue_regs<T>(p, acc, bv, m0, n0, wm, wn, fr, fq, mt * 2 + wm, split, res_done);
 #ifdef PM_RING_PROF
@@ -1146,6 +1150,9 @@ __global__ __launch_bounds__(512, 1) void gemm_ringw_kernel(const GemmParams p) 
       if (AMODE == A_DENSE && !res_done && epilogue_lean16_ok(p, m_eff, n0 + wn * 64) && m_eff + 128 <= p.M) {
         epilogue_lean16<T>(p, acc0, bv, m_eff, n0 + wn * 64, fr, fq);  // (r06: see gemm_kernel)
         epilogue_lean16<T>(p, acc1, bv, m_eff + 64, n0 + wn * 64, fr, fq);
+      } else if (epilogue_lean32_ok(p, m_eff, n0 + wn * 64, res_done) && m_eff + 128 <= p.M) {
+        epilogue_lean32<T>(p, acc0, bv, m_eff, n0 + wn * 64, fr, fq, m_eff >> 6, split);
+        epilogue_lean32<T>(p, acc1, bv, m_eff + 64, n0 + wn * 64, fr, fq, (m_eff + 64) >> 6, split);
       } else {
         epilogue_regs<T>(p, acc0, bv, m_eff, n0, 0, wn, fr, fq, m_eff >> 6, split, res_done);
         epilogue_regs<T>(p, acc1, bv, m_eff + 64, n0, 0, wn, fr, fq, (m_eff + 64) >> 6, split, res_done);

@@ -639,6 +639,76 @@ __device__ __forceinline__ void epilogue_lean16(const GemmParams& p, f32x4 (&acc
   }
 }
 
+// LEAN epilogue of the all-f32 flavours (r06): f32 output (or a split-K slab) in natural column order, bias add, no activation, f32
+// residual none or already inside the accumulators (residual_into_acc), GroupNorm column statistics optional - i.e. what every
+// 3x3 / temporal conv and every out-projection onto the residual stream ends with.  Same idea as epilogue_lean16: the piece lies
+// wholly inside the matrix, so one base pointer per lane, a constant row step, unconditional 16-byte accesses (lane (fr, fq), block
+// j <-> the 4 floats at column 16 j + 4 fq: the four fq lanes of a row cover 64 contiguous bytes per instruction).
+__device__ __forceinline__ bool epilogue_lean32_ok(const GemmParams& p, int m_p, int n_p, bool res_done) {
+  if (!p.natural || m_p + 64 > p.M || n_p + 64 > p.N) return false;
+  if (p.splits > 1) return (p.N & 3) == 0;
+  if (!p.out32 || p.act != PM_ACT_NONE || p.bias_mul || (p.ldc & 3)) return false;
+  return p.R == nullptr || res_done;  // (a residual not yet inside the accumulators stays with epilogue_regs: its 32 registers of
+                                      //  loads in flight on top of the statistics push the callers over 256 VGPRs)
+}
+template <typename T>
+__device__ __forceinline__ void epilogue_lean32(const GemmParams& p, f32x4 (&acc)[4][4], const float (&bv)[4][4], int m_p, int n_p,
+                                                int fr, int fq, int sblock, int split) {
+  const bool partial = p.splits > 1;
+  const int64_t ldc = partial ? p.N : p.ldc;
+  float* cp = (partial ? p.ws + (int64_t)split * p.M * p.N : reinterpret_cast<float*>(p.C)) + (int64_t)(m_p + fr) * ldc + n_p + 4 * fq;
+  const int64_t cstep = 16 * ldc;
+  const bool stats = !partial && p.colstats != nullptr;
+  float cs[2][8], cq[2][8];
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[jp][e] = cq[jp][e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
+      if (stats) {  // (wave-uniform) cs[jp][4 h + r] <-> block 2 jp + h: run_col's natural layout
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          cs[j >> 1][4 * (j & 1) + r] += v[r];
+          cq[j >> 1][4 * (j & 1) + r] = fmaf(v[r], v[r], cq[j >> 1][4 * (j & 1) + r]);
+        }
+      }
+      *reinterpret_cast<f32x4*>(cp + j * 16) = v;
+    }
+    cp += cstep;
+  }
+  if (stats) {  // column sums of this wave's 64 rows: a fixed xor tree over fr (as epilogue_regs)
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          cs[jp][e] += __shfl_xor(cs[jp][e], o, 64);
+          cq[jp][e] += __shfl_xor(cq[jp][e], o, 64);
+        }
+      }
+    if (p.gs_ni > 0) {
+      group_stats_add(p, cs, cq, n_p, p.N, sblock * 64, fr, fq, true);
+    } else if (fr == 0) {
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float* dst = p.colstats + ((int64_t)sblock * p.N + n_p + run_col(jp, h, fq, true)) * 2;
+#pragma unroll
+          for (int e = 4 * h; e < 4 * h + 4; e += 2)
+            *reinterpret_cast<f32x4*>(dst + 2 * (e - 4 * h)) = f32x4{cs[jp][e], cq[jp][e], cs[jp][e + 1], cq[jp][e + 1]};
+        }
+    }
+  }
+}
+
 // gemm256.hip: the 256x256 8-phase kernel for large dense shapes
 bool gemm256_wanted(const GemmParams& p, int flags, int num_cus);
 template <typename T> int launch_gemm256(const GemmParams& p, int num_cus, hipStream_t stream);
