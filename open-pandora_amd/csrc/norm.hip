@@ -199,6 +199,33 @@ __global__ void gn_apply_kernel(const TI* __restrict__ x, int64_t ldx, const flo
   T* yp = y + (int64_t)inst * P * ldy + cv * 8;
   float sc[8], sh[8];
   bool have = false;
+  // integer totals (PM_TOTALS_I64): `nsum` partial entries of 4 limbs per group, a 64-byte sector each.  One thread per (group,
+  // limb) sums its entries - independent loads, one round trip - and one thread per group turns the limbs into {mean, rstd} in
+  // LDS (every thread walking all 4 nsum limbs of its groups itself: 64 dependent-looking loads in front of the first store,
+  // +7 us per launch at nsum = 16)
+  __shared__ long long s_limb[512];  // (groups <= 128: pm_groupnorm_apply)
+  __shared__ float s_mr[256];
+  if (nsum > 0) {
+    const long long* ti = reinterpret_cast<const long long*>(totals);
+    for (int idx = threadIdx.x; idx < groups * 4; idx += blockDim.x) {
+      const long long* lp = ti + ((int64_t)inst * nsum * groups * 4 + idx) * GS_STRIDE;
+      long long acc = 0;
+      for (int f = 0; f < nsum; ++f) acc += lp[(int64_t)f * groups * 4 * GS_STRIDE];
+      s_limb[idx] = acc;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < groups) {
+      const int g = threadIdx.x;
+      const double sum = (double)s_limb[4 * g] * GS_INV_A + (double)s_limb[4 * g + 1] * GS_INV_B;
+      const double sq = (double)s_limb[4 * g + 2] * GS_INV_A + (double)s_limb[4 * g + 3] * GS_INV_B;
+      const double md = sum * (double)inv_count;
+      double var = sq * (double)inv_count - md * md;
+      if (var < 0.0) var = 0.0;
+      s_mr[2 * g] = (float)md;
+      s_mr[2 * g + 1] = rsqrtf((float)var + eps);
+    }
+    __syncthreads();
+  }
   for (int r = r0 + rlane; r < r1; r += 4 * k) {
     float t[4][8];
 #pragma unroll
@@ -221,21 +248,8 @@ __global__ void gn_apply_kernel(const TI* __restrict__ x, int64_t ldx, const flo
         if (g != gprev) {  // (a new group: at most two per 8-channel column once a group has >= 8 channels)
           gprev = g;
           if (nsum > 0) {
-            const long long* ti = reinterpret_cast<const long long*>(totals);
-            long long sa = 0, sb = 0, qa = 0, qb = 0;
-            for (int f = 0; f < nsum; ++f) {
-              const long long* t4 = ti + (((int64_t)inst * nsum + f) * groups + g) * 4 * GS_STRIDE;
-              sa += t4[0];
-              sb += t4[GS_STRIDE];
-              qa += t4[2 * GS_STRIDE];
-              qb += t4[3 * GS_STRIDE];
-            }
-            const double sum = (double)sa * GS_INV_A + (double)sb * GS_INV_B, sq = (double)qa * GS_INV_A + (double)qb * GS_INV_B;
-            const double md = sum * (double)inv_count;
-            double var = sq * (double)inv_count - md * md;
-            if (var < 0.0) var = 0.0;
-            mean = (float)md;
-            rstd = rsqrtf((float)var + eps);
+            mean = s_mr[2 * g];
+            rstd = s_mr[2 * g + 1];
           } else {
             const float a = totals[((int64_t)inst * groups + g) * 2];
             const float bq = totals[((int64_t)inst * groups + g) * 2 + 1];
