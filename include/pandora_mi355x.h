@@ -68,7 +68,9 @@ extern "C" {
                              * `flags`; M % NI == 0, rows per instance a multiple of pm_gemm_colstats_rows, N % 32 == 0) that the epilogue ADDS the
                              * GroupNorm sums of the stored values to - per (instance, group of N/32 columns): {sum, sumsq} as two
                              * fixed-point limbs each (2^-12 and 2^-44 units, element 0 of a 64-byte sector each; integer atomics: the totals do not depend on arrival order).
-                             * The caller zeroes the buffer; pm_groupnorm_apply reads it with PM_TOTALS_I64.  No finalize launch. */
+                             * The caller zeroes the buffer; pm_groupnorm_apply reads it with PM_TOTALS_I64.  No finalize launch.
+                             * Shipped library: honoured on split-K plans (pm_gemm_colstats_rows == 16: the reduce pass adds the totals); an unsplit call
+                             * returns PM_E_SHAPE - the MFMA epilogues carry the atomics in the diagnostics build only (a measured loss). */
 #define PM_TOTALS_I64 0x200 /* OR-ed into the in_dtype of pm_groupnorm_stats (totals = int64 limbs as above, added to; `partials` unused)
                              * and into the out_dtype of pm_groupnorm_apply (totals = int64 limbs; bits 16..23 of out_dtype = nsum >= 1:
                              * instance i uses the integer sum of entries i*nsum .. i*nsum + nsum - 1, e.g. per-frame sums -> clip sums) */

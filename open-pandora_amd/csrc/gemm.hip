@@ -1623,6 +1623,7 @@ extern "C" int pm_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, c
   // bytes would poison the accumulator, so require a real zero source only when a tail exists.
   if (K % BK) return PM_E_SHAPE;  // all Linear layers on the path have K % 64 == 0
   plan_split(p, workspace, workspace_bytes);
+  if (!GS_EPILOGUE && p.gs_ni > 0 && p.splits <= 1) return PM_E_SHAPE;  // (integer totals from an unsplit call: diagnostics build only)
   if (p.colstats != nullptr && p.splits > 1 && ((p.ldc & 3) || (p.R != nullptr && (p.ldr & 3)))) return PM_E_SHAPE;
   // the 16-bit projection flavours on whole 256 x 256 tiles: the assembly kernel with the K stream continuous across tiles
   if (gemm_wide_stream_wanted(p, flags, num_cus()))
@@ -1674,6 +1675,7 @@ extern "C" int pm_conv2d_3x3(const void* x, int64_t ldx, const void* Wp, const f
     p.tap_w[t] = (int64_t)t * Cin * 2;
   }
   plan_split(p, workspace, workspace_bytes, /*two_stage=*/upsample2x || (Cin % BK) != 0);
+  if (!GS_EPILOGUE && p.gs_ni > 0 && p.splits <= 1) return PM_E_SHAPE;  // (integer totals from an unsplit call: diagnostics build only)
   if (p.colstats != nullptr && p.splits > 1 && ((p.ldc & 3) || (p.R != nullptr && (p.ldr & 3)))) return PM_E_SHAPE;
   if (!upsample2x && (Cin % BK) == 0)
     PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_CONV3X3_FAST>(p, flags, (hipStream_t)stream)));
@@ -1725,6 +1727,7 @@ extern "C" int pm_conv_temporal_k3_clips(const void* x, int64_t ldx, const void*
     p.tap_w[t] = (int64_t)t * Cin * 2;
   }
   plan_split(p, workspace, workspace_bytes);
+  if (!GS_EPILOGUE && p.gs_ni > 0 && p.splits <= 1) return PM_E_SHAPE;  // (integer totals from an unsplit call: diagnostics build only)
   if (p.colstats != nullptr && p.splits > 1 && ((p.ldc & 3) || (p.R != nullptr && (p.ldr & 3)))) return PM_E_SHAPE;
   PM_DISPATCH_DTYPE(dtype, T, return (launch<T, A_CONVT3>(p, flags, (hipStream_t)stream)));
 }

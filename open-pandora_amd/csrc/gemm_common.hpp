@@ -79,6 +79,10 @@ constexpr int GS_STRIDE = 8;
 constexpr float GS_SCALE_A = 4096.0f;                 // 2^12
 constexpr float GS_SCALE_B = 17592186044416.0f;       // 2^44
 constexpr double GS_INV_A = 1.0 / 4096.0, GS_INV_B = 1.0 / 17592186044416.0;
+// The MFMA kernels' epilogues carry the atomics only in the diagnostics build (PANDORA_STATS_I64=2, an A/B that lost: +1 ... +3 % per
+// step, profiles/r06/stats_i64_ab.txt): compiled in, the path costs the 256x128 ring conv kernels 10 more spilled registers
+// (13 -> 23) and 9 - 13 % of their time whether it is taken or not.  The split-K reduce pass and the statistics pass keep them.
+constexpr bool GS_EPILOGUE = PM_DIAG_BUILD;
 __device__ __forceinline__ void gs_atomic_add(long long* dst, float p) {
   const float a = rintf(p * GS_SCALE_A);
   const float r = fmaf(-a, 1.0f / GS_SCALE_A, p);  // exact: p minus its rounding to the 2^-12 grid
@@ -396,7 +400,7 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, f32x4 (&acc)[
             cq[jp][e] += __shfl_xor(cq[jp][e], o, 64);
           }
         }
-      if (p.gs_ni > 0) {  // (r06: group totals by integer atomics, no finalize launch)
+      if (GS_EPILOGUE && p.gs_ni > 0) {  // (r06: group totals by integer atomics, no finalize launch; diagnostics build)
         if (sblock * 64 < p.M)
           group_stats_add(p, cs, cq, ncol0, nout, sblock * 64, fr, fq, out32 && Rg == nullptr && p.natural != 0);
       } else if (fr == 0 && sblock * 64 < p.M) {  // (a ragged last tile has no second block)
@@ -552,7 +556,7 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, f32x4 (&acc)[
             cq[jp][e] += __shfl_xor(cq[jp][e], o, 64);
           }
         }
-      if (p.gs_ni > 0) {
+      if (GS_EPILOGUE && p.gs_ni > 0) {
         if (sblock * 64 < p.M) group_stats_add(p, cs, cq, n0 + wn * 64, nout, sblock * 64, fr, fq, false);
       } else if (fr == 0 && sblock * 64 < p.M) {  // (a ragged last tile has no second block)
 #pragma unroll
@@ -693,7 +697,7 @@ __device__ __forceinline__ void epilogue_lean32(const GemmParams& p, f32x4 (&acc
           cq[jp][e] += __shfl_xor(cq[jp][e], o, 64);
         }
       }
-    if (p.gs_ni > 0) {
+    if (GS_EPILOGUE && p.gs_ni > 0) {
       group_stats_add(p, cs, cq, n_p, p.N, sblock * 64, fr, fq, true);
     } else if (fr == 0) {
 #pragma unroll

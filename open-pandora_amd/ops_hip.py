@@ -102,7 +102,9 @@ class HipOps:
         # forward).  The buffers come from a per-stream arena that `begin_forward` zeroes with ONE memset; outside a forward (or
         # past its end) a call takes a fresh zeroed tensor.  "0": the column-sum + finalize form (A/B runs)
         self.stats_i64 = os.environ.get("PANDORA_STATS_I64", "1") != "0"
-        self.stats_i64_all = os.environ.get("PANDORA_STATS_I64", "1") == "2"  # (A/B: also from the MFMA kernels' epilogues)
+        # "2" (A/B that lost, diagnostics build only - the shipped MFMA kernels do not carry the path): also from their epilogues
+        self.stats_i64_all = (os.environ.get("PANDORA_STATS_I64", "1") == "2" and os.environ.get("PANDORA_DIAG_LIB") == "1"
+                              and "PANDORA_LIB" not in os.environ)
         self.stats_nsum = self.stats_i64  # groupnorm_apply sums consecutive totals entries itself (per-frame -> clip sums)
         self._arena = {}  # stream -> [int64 tensor, next free element]
         self.arena_bytes = 16 << 20
