@@ -324,6 +324,14 @@ int pm_ddim_update(const float* x, const void* e_c, const void* e_u, const float
                    int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * pm_timestep_embedding: the sinusoidal timestep / fps embedding, y[i, j] = cos(t[i] * freqs[j]), y[i, half + j] =
+ * sin(t[i] * freqs[j]) (f32 product, f32 cos / sin), j < half.  replaces timestep_embedding (utils_diffusion.py:8-28) in front
+ * of time_embed / fps_embedding (openaimodel3d.py:554-581): the caller passes the reference's frequency table (its bf16-
+ * quantised arange through exp, built once on the host).  t: n values on the device, int64 (t_is_i64 != 0) or f32.
+ */
+int pm_timestep_embedding(const void* t, int t_is_i64, const float* freqs, float* y, int64_t n, int64_t half, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * layout helpers on the path boundary (DiffusionWrapper 'hybrid' concat ddpm3d.py:1077-1081 and the
  * `b c t h w -> (b t) c h w` shuffles openaimodel3d.py:570,606):
  *   pm_pack_input:  x f32 [C1, F, P] and cond f32 [C2, F, P]  ->  y dtype [F, P, C1 + C2]

@@ -72,6 +72,7 @@ SIGNATURES = {
     "pm_ddim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_int,
                                c_void_p]),
+    "pm_timestep_embedding": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "pm_pack_input": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                               c_int, c_void_p]),
     "pm_unpack_output": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),

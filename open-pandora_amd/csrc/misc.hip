@@ -317,6 +317,33 @@ extern "C" int pm_ddim_update(const float* x, const void* e_c, const void* e_u, 
                     return check_launch());
 }
 
+namespace pm {
+// y[i, j] = cos(t_i f_j), y[i, half + j] = sin(t_i f_j): the product in f32 as the reference forms it, cosf / sinf with full
+// range reduction (t f reaches 1000 rad)
+__global__ __launch_bounds__(256) void timestep_embedding_kernel(const void* __restrict__ t, int is_i64,
+                                                                 const float* __restrict__ freqs, float* __restrict__ y,
+                                                                 int n, int half) {
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n * half; idx += gridDim.x * 256) {
+    const int i = idx / half, j = idx - i * half;
+    const float tv = is_i64 ? (float)reinterpret_cast<const long long*>(t)[i] : reinterpret_cast<const float*>(t)[i];
+    const float a = tv * freqs[j];
+    y[(int64_t)i * 2 * half + j] = cosf(a);
+    y[(int64_t)i * 2 * half + half + j] = sinf(a);
+  }
+}
+}  // namespace pm
+
+extern "C" int pm_timestep_embedding(const void* t, int t_is_i64, const float* freqs, float* y, int64_t n, int64_t half,
+                                     void* stream) {
+  if (!t || !freqs || !y) return PM_E_NULL;
+  if (n < 1 || half < 1 || n * half > (1 << 24)) return PM_E_SHAPE;
+  int64_t nb = (n * half + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(pm::timestep_embedding_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, t, t_is_i64, freqs, y,
+                     (int)n, (int)half);
+  return check_launch();
+}
+
 extern "C" int pm_pack_input(const float* x, const float* cond, void* y, int64_t C1, int64_t C2,
                              int64_t F, int64_t P, int dtype, void* stream) {
   if (!x || !y || (C2 > 0 && !cond)) return PM_E_NULL;

@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256) void gn_finalize_colstats_kernel(const float* 
 // 8-channel column (its scale/shift live in registers: no LDS, no barrier, no index division) and walks
 // rows r0 + rlane, + k, ... with four independent row loads in flight.
 // nsum > 0 (r06): `totals` are int64 fixed-point limbs [NI * nsum][groups][4] (gemm_common.hpp) and instance i uses the SUM of
-// entries i*nsum .. i*nsum + nsum-1 (per-frame sums of a clip add up to its (T,H,W) sums: exact in integers)
+// entries i*nsum .. i*nsum + nsum-1 (per-frame sums of a clip add up to its (T,H,W) sums: exact in integers); nsum < 0: f32
+// {sum, sumsq} entries [NI * -nsum][groups][2] summed the same way (in entry order)
 template <typename TI, typename T>
 __global__ void gn_apply_kernel(const TI* __restrict__ x, int64_t ldx, const float* __restrict__ totals,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -225,6 +226,24 @@ __global__ void gn_apply_kernel(const TI* __restrict__ x, int64_t ldx, const flo
       s_mr[2 * g + 1] = rsqrtf((float)var + eps);
     }
     __syncthreads();
+  } else if (nsum < 0) {  // f32 {sum, sumsq} entries, summed in entry order (a fixed order: the same bits every launch)
+    float* s_f = reinterpret_cast<float*>(s_limb);
+    for (int idx = threadIdx.x; idx < groups * 2; idx += blockDim.x) {
+      const float* lp = totals + (int64_t)inst * (-nsum) * groups * 2 + idx;
+      float acc = 0.f;
+      for (int f = 0; f < -nsum; ++f) acc += lp[(int64_t)f * groups * 2];
+      s_f[idx] = acc;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < groups) {
+      const int g = threadIdx.x;
+      const float mean = s_f[2 * g] * inv_count;
+      float var = s_f[2 * g + 1] * inv_count - mean * mean;
+      if (var < 0.f) var = 0.f;
+      s_mr[2 * g] = mean;
+      s_mr[2 * g + 1] = rsqrtf(var + eps);
+    }
+    __syncthreads();
   }
   for (int r = r0 + rlane; r < r1; r += 4 * k) {
     float t[4][8];
@@ -247,7 +266,7 @@ __global__ void gn_apply_kernel(const TI* __restrict__ x, int64_t ldx, const flo
         const int g = (cv * 8 + e) / cpg;
         if (g != gprev) {  // (a new group: at most two per 8-channel column once a group has >= 8 channels)
           gprev = g;
-          if (nsum > 0) {
+          if (nsum != 0) {
             mean = s_mr[2 * g];
             rstd = s_mr[2 * g + 1];
           } else {
@@ -504,8 +523,10 @@ extern "C" int pm_groupnorm_apply(const void* x, int64_t ldx, const float* total
   if (rc) return rc;
   const int lo_off = (out_dtype & PM_OUT_HILO) ? (int)C : 0;
   // r06: PM_TOTALS_I64 in out_dtype: totals are int64 limbs; bits 16..23 = nsum (entries summed per instance, >= 1)
-  const int nsum = (out_dtype & PM_TOTALS_I64) ? ((out_dtype >> 16) & 0xff) : 0;
+  // without PM_TOTALS_I64: bits 16..23 = n >= 2: f32 totals [NI * n][groups][2], instance i uses the sum of its n entries (0 / 1: one)
+  int nsum = (out_dtype >> 16) & 0xff;
   if ((out_dtype & PM_TOTALS_I64) && nsum < 1) return PM_E_SHAPE;
+  if (!(out_dtype & PM_TOTALS_I64)) nsum = nsum >= 2 ? -nsum : 0;
   out_dtype &= 0xff;
   if ((ldy & 7) || ldy < C + lo_off || count <= 0) return PM_E_SHAPE;
   const int threads = gn_threads((int)(C >> 3));

@@ -382,6 +382,17 @@ class HipOps:
         capi.check(rc, f"pm_gemv_f32 N={N} K={K}")
         return y
 
+    def timestep_embedding(self, t, freqs):
+        """f32 [n, 2 * half] = [cos(t f) | sin(t f)] for n timesteps (int64 or f32 on the device) and the f32 frequency table
+        (utils_diffusion.py:8-28): one launch instead of torch's convert / mul / cos / sin / cat."""
+        assert t.dim() == 1 and t.dtype in (torch.int64, torch.float32) and t.is_contiguous()
+        assert freqs.dtype == torch.float32 and freqs.is_contiguous()
+        n, half = t.numel(), freqs.numel()
+        y = torch.empty(n, 2 * half, dtype=torch.float32, device=self.device)
+        rc = self.lib.pm_timestep_embedding(_ptr(t), int(t.dtype == torch.int64), _ptr(freqs), _ptr(y), n, half, self._stream())
+        capi.check(rc, f"pm_timestep_embedding n={n} half={half}")
+        return y
+
     # -- normalisation ---------------------------------------------------------------------------
     def groupnorm_stats(self, x, NI, groups=32):
         """{sum, sumsq} per (instance, group): f32 [NI, groups, 2] (deterministic two-level sum)."""
@@ -416,8 +427,11 @@ class HipOps:
             nsum = totals.shape[0] // NI
             assert totals.shape == (NI * nsum, groups, 4, 8) and totals.is_contiguous() and 1 <= nsum <= 255
             odt |= capi.PM_TOTALS_I64 | (nsum << 16)
-        else:
-            assert totals.shape == (NI, groups, 2) and totals.is_contiguous()
+        else:  # f32 {sum, sumsq}: [NI, groups, 2], or [NI * n, groups, 2] = n entries per instance that the kernel sums (in entry order)
+            nsum = totals.shape[0] // NI
+            assert totals.shape == (NI * nsum, groups, 2) and totals.is_contiguous() and 1 <= nsum <= 255
+            if nsum > 1:
+                odt |= nsum << 16
         rc = self.lib.pm_groupnorm_apply(_ptr(x), self._rows(x, True), _ptr(totals), _ptr(gamma),
                                          _ptr(beta), _ptr(out), self._rows(out), NI, P, C, groups,
                                          float(count), float(eps), int(silu), self._in_dt(x), odt,

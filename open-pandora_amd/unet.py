@@ -47,6 +47,20 @@ def timestep_embedding(timesteps, dim, max_period=10000):
     return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
 
 
+def _timestep_row(ops, t, dim):
+    """Row 0 of the embedding through the op table's one-launch kernel (pm_timestep_embedding) where it has one."""
+    fn = getattr(ops, "timestep_embedding", None)
+    t = t.to(ops.device)
+    if fn is None:
+        return timestep_embedding(t, dim)[0].contiguous()
+    key = (dim, 10000, str(t.device))
+    if key not in _FREQS:
+        timestep_embedding(t, dim)
+    if t.dtype not in (torch.int64, torch.float32):
+        t = t.float()
+    return fn(t[:1].contiguous(), _FREQS[key])[0]
+
+
 # ------------------------------------------------------------------------------------------------
 # parameter containers: same attribute names / child indices as the reference modules
 # ------------------------------------------------------------------------------------------------
@@ -412,9 +426,9 @@ class UNetModel(packing.PackedWeights, nn.Module):
                     totals = tot
                 elif not per_frame and tot.shape[0] == c.F:
                     # per-frame sums add up to the (T,H,W) sums of their clip: by the apply kernel itself where the op table
-                    # carries integer totals (HipOps.stats_nsum: no reduce launch, exact), else here
-                    if getattr(ops, "stats_nsum", False) and tot.dtype == torch.int64 and c.fp is None:
-                        totals = tot
+                    # sums entries (HipOps.stats_nsum: no reduce launch; exact for the integer totals), else here
+                    if getattr(ops, "stats_nsum", False) and c.fp is None:
+                        totals = tot  # (int64 limbs or f32 sums alike: entries b T .. b T + T - 1 belong to clip b)
                     else:
                         totals = tot.sum(0, keepdim=True) if c.B == 1 else tot.view(c.B, c.T, *tot.shape[1:]).sum(1)
         if per_frame:
@@ -627,11 +641,11 @@ class UNetModel(packing.PackedWeights, nn.Module):
         ops, W = c.ops, c.w
         mlp = lambda p, v: ops.gemv(p[1][0], ops.gemv(p[0][0], v, p[0][1], act="silu"), p[1][1])
         dev = ops.device
-        emb = mlp(W["time_embed"], timestep_embedding(timesteps.to(dev), self.model_channels)[0].contiguous())
+        emb = mlp(W["time_embed"], _timestep_row(ops, timesteps, self.model_channels))
         if self.fs_condition:
             if fs is None:
                 fs = torch.tensor([self.default_fs], dtype=torch.long, device=dev)
-            emb = emb + mlp(W["fps_embedding"], timestep_embedding(fs.to(dev), self.model_channels)[0].contiguous())
+            emb = emb + mlp(W["fps_embedding"], _timestep_row(ops, fs, self.model_channels))
         # every ResBlock's  b_conv1 + b_emb + W_emb . silu(emb)  in one launch
         return ops.gemv(W["emb_all"][0], emb, W["emb_all"][1], silu_in=True)
 

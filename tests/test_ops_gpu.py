@@ -445,6 +445,37 @@ def test_groupnorm_external_stats(hip_ops_factory, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_groupnorm_apply_sums_f32_entries(hip_ops_factory, dtype):
+    """pm_groupnorm_apply with n f32 entries per instance (bits 16..23 of out_dtype, no PM_TOTALS_I64): per-frame sums -> the
+    (T,H,W) statistics of each clip without a reduce launch; equal to the pre-summed totals up to the summation order."""
+    ops = hip_ops_factory(dtype)
+    B, T, P, C = 2, 4, 96, 320
+    x = (rnd(B * T * P, C, dtype=torch.float32, seed=1) + 0.5).to(dtype).cuda()
+    gamma = (1 + 0.2 * rnd(C, dtype=torch.float32, seed=2)).cuda()
+    beta = (0.3 * rnd(C, dtype=torch.float32, seed=3)).cuda()
+    per_frame = _f32(ops.groupnorm_stats(x, B * T)).contiguous()  # [B T, 32, 2]
+    want = REF.groupnorm(x.cpu(), gamma.cpu(), beta.cpu(), 1e-5, B, True)
+    count = float(T * P * (C // 32))
+    got = ops.groupnorm_apply(x, per_frame, gamma, beta, 1e-5, B, True, count)
+    assert rel_err(got, want) <= TOL[dtype]
+    pre = per_frame.view(B, T, 32, 2).sum(1).contiguous()
+    ref = ops.groupnorm_apply(x, pre, gamma, beta, 1e-5, B, True, count)
+    assert rel_err(got, ref.cpu()) <= 2e-3 * TOL[dtype] + 1e-6
+
+
+def test_timestep_embedding(hip_ops_factory):
+    """pm_timestep_embedding == the reference's cos / sin of t x (bf16-quantised) frequencies (utils_diffusion.py:8-28)."""
+    from open_pandora_amd.unet import timestep_embedding, _FREQS
+    ops = hip_ops_factory(torch.bfloat16)
+    for t in (torch.tensor([999, 0, 417], dtype=torch.int64), torch.tensor([24.0, 3.0], dtype=torch.float32)):
+        want = timestep_embedding(t, 320)
+        freqs = _FREQS[(320, 10000, "cpu")].cuda()
+        got = ops.timestep_embedding(t.cuda(), freqs)
+        assert got.shape == want.shape
+        assert (got.cpu() - want).abs().max().item() <= 2e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,C", [(333, 320), (50, 1280), (7, 512), (100, 640)])
 def test_layernorm(hip_ops_factory, dtype, M, C):
     ops = hip_ops_factory(dtype)
