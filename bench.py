@@ -153,6 +153,8 @@ class TimedOps:
         ch = o.lib.pm_gemm_kernel_choice(a.shape[0], w.shape[0], k_eff, 2 if act == "geglu" else 0,
                                          1 if f32_loader else 0, o.ws_bytes)
         name = ("gemm_kernel<A_DENSE, f32 operand> (register-staged)" if f32_loader else
+                "gemm_wide_stream_kernel (256x256 tile, 128x128 wave tiles, one assembly statement per workgroup)" if ch == 5 else
+                "gemm_wide_kernel (256x256 tile, assembly K loop per tile)" if ch == 4 else
                 "gemm256_kernel (256x256, 8 waves, ping-pong phases)" if ch == 2 else
                 "gemm_ringw_kernel<A_DENSE> (256x128 ring, 4 loader + 4 consumer waves)" if ch == 3 else
                 "gemm_ring_kernel<A_DENSE>" if ch == 1 else "gemm_kernel<A_DENSE> (128x128, 2 LDS stages, 2 workgroups/CU)")
@@ -162,9 +164,13 @@ class TimedOps:
     def ln_gemm(self, x, gamma, beta, w, *args, **kw):
         # LayerNorm + projection: ONE launch (pm_ln_gemm) at the 320-wide level, counted with its GEMM FLOPs (the
         # normalisation rides in the same kernel); elsewhere the pm_layernorm + pm_gemm pair, whose GEMM is timed
-        if not self._ops.fused_ln or not self._ops.lib.pm_ln_gemm_supported(x.shape[0], w.shape[0], x.shape[1],
-                                                                             2 if kw.get("act") == "geglu" else 0):
-            return self.gemm(self._ops.layernorm(x, gamma, beta), w, *args, **kw)
+        code = 2 if kw.get("act") == "geglu" else 0
+        o = self._ops
+        # (r06: where the projection runs on gemm_wide_stream the op table itself takes the pair, HipOps.ln_gemm)
+        stream_pair = (o.ln_pair_stream and kw.get("col_scale") is None
+                       and o.lib.pm_gemm_kernel_choice(x.shape[0], w.shape[0], x.shape[1], code, 0, o.ws_bytes) == 5)
+        if not o.fused_ln or stream_pair or not o.lib.pm_ln_gemm_supported(x.shape[0], w.shape[0], x.shape[1], code):
+            return self.gemm(o.layernorm(x, gamma, beta), w, *args, **kw)
         fl = 2.0 * x.shape[0] * w.shape[0] * w.shape[1]
         r = self._timed("gemm", fl, self._ops.ln_gemm, x, gamma, beta, w, *args, **kw)
         if not self.enabled:
