@@ -118,7 +118,7 @@ class HipOps:
 
     def _stream(self):
         # raw handle of torch's current stream on this device; the C getter avoids building a Stream object
-        # per launch (a quarter of the host-side cost of an eagerly launched forward, tools/host_profile.py)
+        # per launch (a quarter of the host-side cost of an eagerly launched forward, tools/archive/host_profile.py)
         if self._raw_stream is not None:
             return self._raw_stream(self._dev_index)
         return torch.cuda.current_stream(self.device).cuda_stream
