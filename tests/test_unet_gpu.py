@@ -271,6 +271,49 @@ def test_unet_full_width_forward_40x64(hip_ops_factory, dtype):
     torch.cuda.empty_cache()
 
 
+class _CountingLib:
+    """Counts the C-ABI calls of one forward (a proxy in front of the ctypes handle; split-K calls launch a reduce pass besides)."""
+    QUERIES = ("pm_gemm_kernel_choice", "pm_ln_gemm_supported", "pm_gemm_colstats_rows", "pm_gemm_workspace_bytes",
+               "pm_groupnorm_nchunks", "pm_strerror", "pm_abi_version")
+
+    def __init__(self, lib):
+        self._lib, self.calls = lib, {}
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if name in self.QUERIES:
+            return fn
+
+        def counted(*a):
+            self.calls[name] = self.calls.get(name, 0) + 1
+            return fn(*a)
+        return counted
+
+
+def test_forward_launch_budget_40x64(hip_ops_factory):
+    """the forward's node count is an asserted quantity.  r05: 1052 kernel launches per forward (rocprofv3), of
+    them ~25 torch kernels; r06: 972, every arithmetic one through the C-ABI (`profiles/r06/forward_kernel_breakdown_320x512.txt`).
+    Counted here as C-ABI calls of one eager forward: the bound fails when a change adds launches again."""
+    ops = hip_ops_factory(torch.bfloat16)
+    pm = factory.build_diffusion("320x512", ops, seed=gr.WEIGHT_SEED)
+    ins, cond, _ = gr.sampler_inputs(40, 64)
+    c = {k: [t.cuda() for t in v] for k, v in cond.items()}
+    args = (ins["x_T"].cuda(), torch.tensor([500]).cuda(), c)
+    pm.apply_model(*args, fs=torch.tensor([15]).cuda())  # (packs the weights: one-off calls)
+    real = ops.lib
+    ops.lib = cl = _CountingLib(real)
+    try:
+        pm.apply_model(*args, fs=torch.tensor([15]).cuda())
+    finally:
+        ops.lib = real
+    n = sum(cl.calls.values())
+    print(f"\n[launch budget] {n} C-ABI calls per forward: " + ", ".join(f"{k[3:]} {v}" for k, v in sorted(cl.calls.items())))
+    assert n <= 930, cl.calls
+    assert cl.calls.get("pm_groupnorm_finalize_colstats", 0) <= 120 and cl.calls.get("pm_timestep_embedding", 0) == 2
+    del pm
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("dtype", [torch.float16])
 def test_ddim_full_width_10_steps_40x64(hip_ops_factory, dtype):
     """BASELINE config 1: 320x512, 16 frames, 10 DDIM steps (eta 0, cfg 4) vs the reference CPU run."""
