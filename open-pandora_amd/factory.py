@@ -1,7 +1,5 @@
 """Model assembly for the two shipped resolutions (DynamiCrafter/configs/inference_{512,1024}_v1.0.yaml
 `model.params`): U-Net hyper-parameters, diffusion shell, op-table binding, seeded synthetic weights."""
-import os
-
 import torch
 import yaml
 

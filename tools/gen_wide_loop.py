@@ -15,7 +15,6 @@ i at +32+4i), v192-v255 the staging set P (A pieces q = 0..7, W pieces q = 8..15
 rows and ds_read_b128 of the 16x16x32 fragments).
 
 Waits are placed by a scoreboard: LDS operations retire in order (lgkmcnt, 4 bits), vector-memory loads in order (vmcnt)."""
-import sys
 
 NQ = 16          # staging pieces per wave and K-step (8 A + 8 W), 1 KiB each
 ABUF, WBUF = 32768, 32768
