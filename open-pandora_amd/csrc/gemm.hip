@@ -361,7 +361,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     // split-K slices store raw f32 partials into their slab; bias/act/residual run in the reduce pass
     // (r06: the 16-bit projection flavours - q|k|v with its column scale, plain / bias - on the lean epilogue where the wave's
     // 64 x 64 piece lies inside the matrix: gemm_common.hpp epilogue_lean16)
-    if (AMODE == A_DENSE && !res_done && epilogue_lean16_ok(p, m0 + wm * 64, n0 + wn * 64))
+    if (piece_dead(p, m0 + wm * 64, n0 + wn * 64)) {
+      // (nothing of this wave's piece is inside the matrix)
+    } else if (AMODE == A_DENSE && !res_done && epilogue_lean16_ok(p, m0 + wm * 64, n0 + wn * 64))
       epilogue_lean16<T>(p, acc, bv, m0 + wm * 64, n0 + wn * 64, fr, fq);
     else if (epilogue_lean32_ok(p, m0 + wm * 64, n0 + wn * 64, res_done))  // (the all-f32 flavours of every A mode)
       epilogue_lean32<T>(p, acc, bv, m0 + wm * 64, n0 + wn * 64, fr, fq, mt * WMW + wm, split);
@@ -751,7 +753,8 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmParams p) {
 #endif
 
     // ---------------- epilogue of this wave's 64x64 quadrant (the loaders keep streaming the next tile) ----
-    if (AMODE == A_DENSE && !res_done && epilogue_lean16_ok(p, m0 + wm * 64, n0 + wn * 64))
+    if (piece_dead(p, m0 + wm * 64, n0 + wn * 64)) {
+    } else if (AMODE == A_DENSE && !res_done && epilogue_lean16_ok(p, m0 + wm * 64, n0 + wn * 64))
       epilogue_lean16<T>(p, acc, bv, m0 + wm * 64, n0 + wn * 64, fr, fq);  // (r06: see gemm_kernel)
     else if (epilogue_lean32_ok(p, m0 + wm * 64, n0 + wn * 64, res_done))
       epilogue_lean32<T>(p, acc, bv, m0 + wm * 64, n0 + wn * 64, fr, fq, mt * 2 + wm, split);
@@ -1087,9 +1090,12 @@ __global__ __launch_bounds__(512, 1) void gemm_ringw_kernel(const GemmParams p) 
     if constexpr (AMODE == A_DENSE) load_bias_regs(p, bv, n0, wn, fq);
 
     f32x4 acc0[4][4], acc1[4][4];  // rows m0 + wm*128 + {0, 64} ..
-    const bool res_done = residual_into_acc<T>(p, acc0, m0 + wm * 128, n0, 0, wn, fr, fq);
+    // (dead pieces, gemm_common.hpp piece_dead: skipped in the conv modes only - with the two extra branches the DENSE instance of
+    //  this kernel goes from 21 to 74 spilled registers under hipcc and loses 1 % of a step; the conv instances go from 17 to 0)
+    constexpr bool SKIP_DEAD = AMODE != A_DENSE;
+    const bool res_done = residual_into_acc<T, SKIP_DEAD>(p, acc0, m0 + wm * 128, n0, 0, wn, fr, fq);
     if (res_done) {
-      (void)residual_into_acc<T>(p, acc1, m0 + wm * 128 + 64, n0, 0, wn, fr, fq);
+      (void)residual_into_acc<T, SKIP_DEAD>(p, acc1, m0 + wm * 128 + 64, n0, 0, wn, fr, fq);
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -1147,7 +1153,8 @@ __global__ __launch_bounds__(512, 1) void gemm_ringw_kernel(const GemmParams p) 
     {
       if constexpr (AMODE != A_DENSE) load_bias_regs(p, bv, n0, wn, fq);
       const int m_eff = m0 + wm * 128;
-      if (AMODE == A_DENSE && !res_done && epilogue_lean16_ok(p, m_eff, n0 + wn * 64) && m_eff + 128 <= p.M) {
+      if (SKIP_DEAD && piece_dead(p, m_eff, n0 + wn * 64)) {
+      } else if (AMODE == A_DENSE && !res_done && epilogue_lean16_ok(p, m_eff, n0 + wn * 64) && m_eff + 128 <= p.M) {
         epilogue_lean16<T>(p, acc0, bv, m_eff, n0 + wn * 64, fr, fq);  // (r06: see gemm_kernel)
         epilogue_lean16<T>(p, acc1, bv, m_eff + 64, n0 + wn * 64, fr, fq);
       } else if (epilogue_lean32_ok(p, m_eff, n0 + wn * 64, res_done) && m_eff + 128 <= p.M) {

@@ -271,9 +271,16 @@ __device__ __forceinline__ void store_fast(const GemmParams& p, f32x4 (&acc)[4][
 // the accumulators START from the residual instead of zero: its loads are issued at tile start and land behind the
 // K loop instead of stalling the epilogue (these GEMMs stream A, residual and output once: HBM-latency-bound), and
 // the epilogue then skips the add.  Returns whether it did (the caller zero-fills otherwise).
-template <typename T>
+// A wave's 64 x 64 piece that lies wholly outside the matrix (the second column half of the ragged last column tile of N = 320 /
+// 960 on 128-wide tiles: a third / an eighth of all tiles there) has nothing to load or store: the callers skip its residual
+// prefetch and its epilogue (r06: the generic epilogue walked its ~900 masked instructions - and its clamped residual loads -
+// anyway, and a tile's epilogue ends with its slowest wave).
+__device__ __forceinline__ bool piece_dead(const GemmParams& p, int m_p, int n_p) { return n_p >= p.N || m_p >= p.M; }
+
+template <typename T, bool SKIP_DEAD = true>
 __device__ __forceinline__ bool residual_into_acc(const GemmParams& p, f32x4 (&acc)[4][4], int m0, int n0, int wm,
                                                   int wn, int fr, int fq) {
+  if (SKIP_DEAD && piece_dead(p, m0 + wm * 64, n0 + wn * 64)) return false;
   if (p.R == nullptr || p.splits > 1 || p.act != PM_ACT_NONE || p.bias_mul || (p.N & 7) || (p.ldc & 7) || (p.ldr & 7)) return false;
   const bool f32res = p.res32 != 0;
 #pragma unroll
