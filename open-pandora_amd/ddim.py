@@ -414,22 +414,25 @@ class DDIMSampler:
             cbs = (first[0] if isinstance(first, (list, tuple)) else first).shape[0]
             if cbs != batch_size:
                 print(f"Warning: Got {cbs} conditionings but batch-size is {batch_size}")
-        for flag, name in ((quantize_x0, "quantize_x0"), (score_corrector is not None, "score_corrector"),
-                           (noise_dropout > 0.0, "noise_dropout")):
-            if flag:
-                raise NotImplementedError(f"{name} is not on the Open-Pandora generate() path")
+        if quantize_x0:  # (ddim.py:277-278: first_stage_model.quantize - a VQ first stage; Open-Pandora ships the KL autoencoder)
+            raise NotImplementedError("quantize_x0 needs a VQ first stage; the Open-Pandora first stage is AutoencoderKL")
+        if score_corrector is not None and self._fp() is not None:
+            raise NotImplementedError("score_corrector sees one rank's frames only in frame-sharded mode")
         self.make_schedule(ddim_num_steps=S, ddim_discretize=timestep_spacing, ddim_eta=eta, verbose=schedule_verbose)
         size = (batch_size, *shape)
         return self.ddim_sampling(conditioning, size, callback=callback, img_callback=img_callback, mask=mask,
                                   x0=x0, temperature=temperature, x_T=x_T, log_every_t=log_every_t,
                                   unconditional_guidance_scale=unconditional_guidance_scale,
                                   unconditional_conditioning=unconditional_conditioning, verbose=verbose,
-                                  precision=precision, fs=fs, guidance_rescale=guidance_rescale, **kwargs)
+                                  precision=precision, fs=fs, guidance_rescale=guidance_rescale,
+                                  noise_dropout=noise_dropout, score_corrector=score_corrector,
+                                  corrector_kwargs=corrector_kwargs, **kwargs)
 
     @torch.no_grad()
     def p_sample_ddim(self, x, c, t, index, temperature=1.0, unconditional_guidance_scale=1.0,
                       unconditional_conditioning=None, fs=None, noise=None, want_x0=True, step=None,
-                      guidance_rescale=0.0, cfg_img=None, unconditional_conditioning_img_nonetext=None, **kwargs):
+                      guidance_rescale=0.0, cfg_img=None, unconditional_conditioning_img_nonetext=None,
+                      noise_dropout=0.0, score_corrector=None, corrector_kwargs=None, **kwargs):
         """One denoising step (ddim.py:218-290): two U-Net forwards when CFG is on, then the fused
         update kernel.  `t` is the (b,) long tensor of the current DDPM timestep, `index` its position
         in the DDIM schedule.  `noise` (f32, x-shaped) overrides the device RNG draw."""
@@ -580,6 +583,13 @@ class DDIMSampler:
                 ratio = (std(tot[0], tot[1]) / std(tot[2], tot[3])).to(v.dtype)
             v = guidance_rescale * (v * ratio) + (1.0 - guidance_rescale) * v
             e_c, e_u, cfg_scale = v, None, 1.0
+        if score_corrector is not None:
+            # ddim.py:248-250: the finished model output (guided, rescaled) goes through the corrector's modify_score before the
+            # update - eps parameterisation only, as the reference asserts; the fused update kernel then takes e_t as it is
+            assert self.model.parameterization == "eps", 'not implemented'
+            e_t = e_c if e_u is None else e_u + cfg_scale * (e_c - e_u)
+            e_t = score_corrector.modify_score(self.model, e_t, x, t, c, **(corrector_kwargs or {}))
+            e_c, e_u, cfg_scale = e_t.to(torch.float32), None, 1.0
         sc = self.step_scalars(index, step)
         if sc["sigma"] != 0.0:
             if noise is None:
@@ -590,6 +600,8 @@ class DDIMSampler:
                     clip = tuple(x.shape[:2]) + (fp.total_frames,) + tuple(x.shape[3:])
                     noise = fp.shard_frames(self._draw(clip, ops.device))
             noise = noise.to(device=ops.device, dtype=torch.float32).contiguous()
+            if noise_dropout > 0.0:  # ddim.py:283-284 drops elements of sigma * noise * temperature: the scalars commute with the mask
+                noise = torch.nn.functional.dropout(noise, p=noise_dropout).contiguous()
             sc["sigma"] *= float(temperature)
         else:
             noise = None
@@ -600,7 +612,8 @@ class DDIMSampler:
     def ddim_sampling(self, cond, shape, x_T=None, callback=None, mask=None, x0=None, img_callback=None,
                       log_every_t=100, temperature=1.0, unconditional_guidance_scale=1.0,
                       unconditional_conditioning=None, verbose=True, precision=None, fs=None,
-                      noise_fn=None, guidance_rescale=0.0, **kwargs):
+                      noise_fn=None, guidance_rescale=0.0, noise_dropout=0.0, score_corrector=None, corrector_kwargs=None,
+                      **kwargs):
         ops = self._ops()
         device = ops.device
         img = self._draw(shape, device) if x_T is None else x_T.to(device)
@@ -655,7 +668,9 @@ class DDIMSampler:
                                               unconditional_guidance_scale=unconditional_guidance_scale,
                                               unconditional_conditioning=unconditional_conditioning, fs=fs,
                                               noise=noise, step=step,
-                                              guidance_rescale=guidance_rescale, **model_kwargs)
+                                              guidance_rescale=guidance_rescale, noise_dropout=noise_dropout,
+                                              score_corrector=score_corrector, corrector_kwargs=corrector_kwargs,
+                                              **model_kwargs)
             if callback:
                 callback(i)
             if img_callback:

@@ -60,9 +60,10 @@ def ddim_tables(tables, S, eta, spacing):
 @torch.no_grad()
 def ddim_sample(apply_model, tables, x_T, cond, uncond, S, eta, cfg_scale, spacing="uniform_trailing",
                 noises=None, fs=None, keep_pred_x0=False, guidance_rescale=0.0, uncond_img=None, cfg_img=None,
-                parameterization="v"):
+                parameterization="v", score_corrector=None, corrector_kwargs=None, noise_dropout=0.0):
     """apply_model(x, t, cond, fs) -> v prediction.  noises: list of S tensors (one per loop
-    iteration, same shape as x_T) consumed when eta > 0.  Returns (x_0 sample, [pred_x0 per step])."""
+    iteration, same shape as x_T) consumed when eta > 0.  Returns (x_0 sample, [pred_x0 per step]).
+    score_corrector / corrector_kwargs / noise_dropout: ddim.py:248-250, 283-284."""
     d = ddim_tables(tables, S, eta, spacing)
     x = x_T.clone().float()
     b = x.shape[0]
@@ -98,12 +99,16 @@ def ddim_sample(apply_model, tables, x_T, cond, uncond, S, eta, cfg_scale, spaci
             pred_x0 = sa * x - sm * v
         else:  # eps (ddim.py:245-246,265-266): the model output IS e_t; x0 from the DDIM tables of this step
             e_t = v
+            if score_corrector is not None:  # ddim.py:248-250 (asserted eps-only there)
+                e_t = score_corrector.modify_score(None, e_t, x, t, cond, **(corrector_kwargs or {}))
             a_t = full(d["alphas"][index])
             pred_x0 = (x - full(torch.sqrt(1.0 - d["alphas"])[index]) * e_t) / a_t.sqrt()
         a_prev, sigma_t = full(d["alphas_prev"][index]), full(d["sigmas"][index])
         pred_x0 = pred_x0 * (full(d["scale_prev"][index]) / full(d["scale"][index]))
         dir_xt = (1.0 - a_prev - sigma_t ** 2).sqrt() * e_t
         noise = sigma_t * (noises[i].to(x.dtype) if noises is not None else torch.zeros_like(x))
+        if noise_dropout > 0.0:  # ddim.py:283-284
+            noise = torch.nn.functional.dropout(noise, p=noise_dropout)
         x = a_prev.sqrt() * pred_x0 + dir_xt + noise
         if keep_pred_x0:
             trace.append(pred_x0)

@@ -17,6 +17,10 @@ UNET_256_OVERRIDES = dict(image_cross_attention_scale_learnable=True, default_fs
 SHELL_256 = dict(parameterization=None, rescale_betas_zero_snr=None, use_dynamic_rescale=None, base_scale=None,
                  fps_condition_type=None, perframe_ae=None, image_size=[32, 32])
 DDIM_EPS_CASES = ((5, 0.0, 4.0), (20, 1.0, 7.5))
+# sampler options of p_sample_ddim (ddim.py:248-250 score_corrector, :283-284 noise_dropout) on the eps model: (S, eta, cfg, which)
+DDIM_OPTION_CASES = ((10, 1.0, 4.0, "score_corrector"), (10, 1.0, 4.0, "noise_dropout"), (8, 1.0, 7.5, "both"))
+CORRECTOR_KWARGS = dict(gain=0.9, mix=0.05)
+NOISE_DROPOUT_P, DROPOUT_SEED = 0.25, 4242
 DDIM_SMALL_CASES = ((5, 0.0, 4.0), (10, 0.0, 4.0), (20, 1.0, 4.0), (10, 0.0, 1.0), (10, 1.0, 4.0))
 FRAMES_SMALL_CASES = ((5, 0.0), (50, 1.0))  # (S, eta): sampler -> decode_first_stage, cfg 4
 DDIM_RESCALE_CASES = ((5, 0.0, 4.0, 0.7), (20, 1.0, 4.0, 0.3))  # (S, eta, cfg, guidance_rescale)
@@ -185,3 +189,29 @@ def ae_latent(T, h, w):
 def ae_pixels(n, H, W):
     """conditioning frames (n, 3, H, W) in [-1, 1]."""
     return synth.uniform_pm1(n * 3 * H * W, INPUT_SEED, f"ae/x/{n}x{H}x{W}").reshape(n, 3, H, W)
+
+
+
+class RecipeCorrector:
+    """A deterministic `score_corrector` (the reference only asks for modify_score(model, e_t, x, t, c, **kwargs), ddim.py:250)."""
+
+    def modify_score(self, model, e_t, x, t, c, gain=1.0, mix=0.0):
+        return gain * e_t + mix * x
+
+
+class RecipeDropout:
+    """Stands in for torch.nn.functional.dropout while a fixture is generated AND while it is checked: the k-th call keeps the
+    elements of a mask drawn from a generator seeded with DROPOUT_SEED + k and scales them by 1 / (1 - p) - what dropout does,
+    without tying the fixture to the order in which a sampler consumes the global RNG."""
+
+    def __init__(self):
+        self.calls = 0
+
+    def __call__(self, input, p=0.5, training=True, inplace=False):
+        import torch
+        if not training or p == 0.0:  # (nn.Dropout modules of an eval-mode network land here too)
+            return input
+        g = torch.Generator().manual_seed(DROPOUT_SEED + self.calls)
+        self.calls += 1
+        keep = (torch.rand(input.shape, generator=g) >= p).to(device=input.device, dtype=input.dtype)
+        return input * keep / (1.0 - p)

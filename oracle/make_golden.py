@@ -172,6 +172,45 @@ def gen_ddim_eps():
     save("ddim_small_eps.npz", **out)
 
 
+def gen_ddim_options():
+    """p_sample_ddim's `score_corrector` (ddim.py:248-250, eps parameterisation only) and `noise_dropout` (:283-284) through the
+    REAL sampler on the 256 model's eps path (as gen_ddim_eps).  The corrector and the dropout mask are the seeded recipes of
+    golden_recipe.py (torch.nn.functional.dropout is replaced by RecipeDropout for the run: the fixture does not depend on the
+    order in which a sampler consumes the global RNG)."""
+    import yaml
+    rh._install_shims()
+    import lvdm.models.samplers.ddim as refddim
+    with open(os.path.join(rh.REFERENCE_ROOT, "DynamiCrafter", "configs", "inference_256_v1.0.yaml")) as f:
+        kw = yaml.safe_load(f)["model"]["params"]["unet_config"]["params"]
+    m = rh.reference_diffusion(dict(kw, model_channels=64, use_checkpoint=False), shell=gr.SHELL_256)
+    assert m.parameterization == "eps"
+    m.model.diffusion_model.load_state_dict(synth.synth_state_dict(m.model.diffusion_model, seed=WEIGHT_SEED))
+    ins, cond, uc = _small_setup()
+    out = {}
+    real_dropout = torch.nn.functional.dropout
+    try:
+        for S, eta, cfg, which in gr.DDIM_OPTION_CASES:
+            noises = iter(gr.noises(ins["x_T"].shape, S))
+            refddim.noise_like = lambda shape, device, repeat=False: next(noises)
+            torch.nn.functional.dropout = gr.RecipeDropout()
+            opt = {}
+            if which in ("score_corrector", "both"):
+                opt.update(score_corrector=gr.RecipeCorrector(), corrector_kwargs=dict(gr.CORRECTOR_KWARGS))
+            if which in ("noise_dropout", "both"):
+                opt.update(noise_dropout=gr.NOISE_DROPOUT_P)
+            smp = rh.reference_sampler(m)
+            y, _ = smp.sample(S=S, batch_size=1, shape=(4, 16, 8, 8), conditioning=cond, verbose=False,
+                              unconditional_guidance_scale=cfg, unconditional_conditioning=uc, eta=eta, fs=torch.tensor([3]),
+                              timestep_spacing="uniform_trailing", x_T=ins["x_T"], **opt)
+            if which != "score_corrector":
+                assert torch.nn.functional.dropout.calls == S
+            out[f"S{S}_eta{eta:g}_cfg{cfg:g}_{which}"] = y.numpy()
+            print(f"options {which} S={S} eta={eta} cfg={cfg}: std {y.std():.4f}")
+    finally:
+        torch.nn.functional.dropout = real_dropout
+    save("ddim_small_options.npz", **out)
+
+
 def gen_clip_hf():
     """The image tower against a THIRD-PARTY implementation that is present in this image: HF `transformers.CLIPVisionModel`
     (the class that loads the laion/CLIP-ViT-H-14-laion2B-s32B-b79K conversion of the very checkpoint the reference pulls
@@ -562,6 +601,7 @@ if __name__ == "__main__":
     ap.add_argument("--full-72x128", action="store_true")
     ap.add_argument("--ctx", action="store_true")
     ap.add_argument("--eps", action="store_true", help="the 256 model's eps-parameterised sampler path (reduced width)")
+    ap.add_argument("--ddim-options", action="store_true", help="score_corrector / noise_dropout on the eps sampler path")
     ap.add_argument("--clip-hf", action="store_true", help="image tower fixtures from transformers' CLIPVisionModel")
     ap.add_argument("--learnable", action="store_true", help="image_cross_attention_scale_learnable fixtures (256 yaml)")
     ap.add_argument("--traj-72x128", type=int, default=0)
@@ -594,6 +634,10 @@ if __name__ == "__main__":
         if a.frames_full:
             gen_frames_full([(int(c.split(":")[0]), float(c.split(":")[1])) for c in a.frames_full.split(",")],
                             forwards=a.with_forwards)
+        sys.exit(0)
+    if a.ddim_options:
+        assert rh.available()
+        gen_ddim_options()
         sys.exit(0)
     if a.eps:
         assert rh.available()

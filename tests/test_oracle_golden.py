@@ -226,6 +226,57 @@ def test_oracle_72x128_fixture_matches_the_real_reference():
         assert np.allclose(a[f"cond/{k}"], b[f"cond/{k}"], rtol=2e-5, atol=2e-5 * float(a["cond/std"]))
 
 
+def _option_kwargs(which):
+    opt = {}
+    if which in ("score_corrector", "both"):
+        opt.update(score_corrector=gr.RecipeCorrector(), corrector_kwargs=dict(gr.CORRECTOR_KWARGS))
+    if which in ("noise_dropout", "both"):
+        opt.update(noise_dropout=gr.NOISE_DROPOUT_P)
+    return opt
+
+
+@pytest.mark.parametrize("S,eta,cfg,which", gr.DDIM_OPTION_CASES)
+def test_ddim_sampler_options_against_reference(S, eta, cfg, which, monkeypatch):
+    """`score_corrector` / `corrector_kwargs` (ddim.py:248-250) and `noise_dropout` (:283-284) of DDIMSampler.sample against the
+    REAL sampler on the 256 yaml's eps path (oracle/make_golden.py --ddim-options; the dropout mask is golden_recipe's seeded
+    stand-in for torch.nn.functional.dropout on both sides): the oracle's restatement, and the PRODUCT sampler on the oracle's
+    op table.  A v-parameterised model with a corrector fails the reference's own assertion."""
+    from oracle.ops_torch import TorchOps
+    from open_pandora_amd.ddim import DDIMSampler
+    from open_pandora_amd.ddpm import LatentVisualDiffusion
+    torch.set_num_threads(4)
+    want = load("ddim_small_options.npz")[f"S{S}_eta{eta:g}_cfg{cfg:g}_{which}"]
+    assert np.isfinite(want).all()
+    kw = dict(RH_KW, model_channels=64, **gr.UNET_256_OVERRIDES)
+    m = U.UNetModel(**kw).eval()
+    sd = synth.synth_state_dict(m, seed=gr.WEIGHT_SEED)
+    tables = ddim_ref.schedule_tables(zero_snr=False, dynamic_rescale=False)
+    ins, cond, uc = gr.sampler_inputs(8, 8)
+    apply = lambda x, t, c, fs: unet_ref.unet_forward(sd, torch.cat([x] + c["c_concat"], 1), t, torch.cat(c["c_crossattn"], 1), fs,
+                                                      model_channels=64)
+    ns = gr.noises(ins["x_T"].shape, S)
+    monkeypatch.setattr(torch.nn.functional, "dropout", gr.RecipeDropout())
+    y, _ = ddim_ref.ddim_sample(apply, tables, ins["x_T"], cond, uc, S, eta, cfg, noises=ns, fs=torch.tensor([3]),
+                                parameterization="eps", **_option_kwargs(which))
+    assert rel(y, want) < 5e-5
+    m.load_state_dict(sd)
+    pm = LatentVisualDiffusion(m.bind(TorchOps()), parameterization="eps", rescale_betas_zero_snr=False, use_dynamic_rescale=False,
+                               image_size=(32, 32))
+    monkeypatch.setattr(torch.nn.functional, "dropout", gr.RecipeDropout())
+    y2, _ = DDIMSampler(pm).sample(S=S, batch_size=1, shape=(4, 16, 8, 8), conditioning=cond, verbose=False,
+                                   unconditional_guidance_scale=cfg, unconditional_conditioning=uc, eta=eta, fs=torch.tensor([3]),
+                                   timestep_spacing="uniform_trailing", x_T=ins["x_T"], noise_fn=lambda i, shape: ns[i],
+                                   **_option_kwargs(which))
+    assert rel(y2, want) < 5e-5
+    if which == "score_corrector":  # the reference asserts the eps parameterisation (ddim.py:249); so does the product
+        pv = LatentVisualDiffusion(m, parameterization="v", rescale_betas_zero_snr=False, use_dynamic_rescale=False,
+                                   image_size=(32, 32))
+        with pytest.raises(AssertionError):
+            DDIMSampler(pv).sample(S=2, batch_size=1, shape=(4, 16, 8, 8), conditioning=cond, verbose=False, eta=0.0,
+                                   fs=torch.tensor([3]), timestep_spacing="uniform_trailing", x_T=ins["x_T"],
+                                   score_corrector=gr.RecipeCorrector())
+
+
 @pytest.mark.parametrize("S,eta,cfg", gr.DDIM_EPS_CASES)
 def test_ddim_eps_parameterisation_against_reference(S, eta, cfg):
     """The 256 yaml's sampler path (eps-prediction, no zero-terminal-SNR rescale, no dynamic rescale; ddim.py:243-246,265-266)

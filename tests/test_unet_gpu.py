@@ -96,6 +96,36 @@ def test_ddim_eps_parameterisation_trajectory(hip_ops_factory, dtype, S, eta, cf
     assert err <= EPS_TRAJ_TOL[(S, dtype)]
 
 
+@pytest.mark.parametrize("S,eta,cfg,which", gr.DDIM_OPTION_CASES)
+def test_ddim_sampler_options_trajectory(hip_ops_factory, S, eta, cfg, which, monkeypatch):
+    """DDIMSampler.sample(score_corrector=..., corrector_kwargs=..., noise_dropout=...) on the kernels (ddim.py:248-250, 283-284)
+    against the REAL sampler's fixture (tests/golden/ddim_small_options.npz; eps path of the 256 yaml, f16): the corrector sees
+    the guided model output before the fused update, the dropout mask (golden_recipe's seeded stand-in on both sides) hits the
+    step's noise.  Tolerance = 1.3 x measured (1.8e-3 / 1.8e-3 / 2.6e-3), as the eps trajectories'."""
+    dtype = torch.float16
+    g = load("ddim_small_options.npz")[f"S{S}_eta{eta:g}_cfg{cfg:g}_{which}"]
+    m = UNetModel(**dict(RH_KW, model_channels=64, **gr.UNET_256_OVERRIDES)).eval()
+    m.load_state_dict(synth.synth_state_dict(m, seed=gr.WEIGHT_SEED))
+    pm = LatentVisualDiffusion(m.bind(hip_ops_factory(dtype)), parameterization="eps", rescale_betas_zero_snr=False,
+                               use_dynamic_rescale=False, image_size=(32, 32))
+    ins, cond, uc = gr.sampler_inputs(8, 8)
+    ns = gr.noises(ins["x_T"].shape, S)
+    dev = lambda c: {k: [v.cuda() for v in lst] for k, lst in c.items()}
+    opt = {}
+    if which in ("score_corrector", "both"):
+        opt.update(score_corrector=gr.RecipeCorrector(), corrector_kwargs=dict(gr.CORRECTOR_KWARGS))
+    if which in ("noise_dropout", "both"):
+        opt.update(noise_dropout=gr.NOISE_DROPOUT_P)
+    monkeypatch.setattr(torch.nn.functional, "dropout", gr.RecipeDropout())
+    y, _ = DDIMSampler(pm).sample(S=S, batch_size=1, shape=(4, 16, 8, 8), conditioning=dev(cond), verbose=False,
+                                  unconditional_guidance_scale=cfg, unconditional_conditioning=dev(uc), eta=eta,
+                                  fs=torch.tensor([3]).cuda(), timestep_spacing="uniform_trailing", x_T=ins["x_T"].cuda(),
+                                  noise_fn=lambda i, shape: ns[i], **opt)
+    err = rel(y.cpu(), g)
+    print(f"\n[parity] ddim sampler options ({which}) S={S} eta={eta} cfg={cfg} {dtype}: rel err {err:.2e}")
+    assert err <= {"score_corrector": 2.4e-3, "noise_dropout": 2.4e-3, "both": 3.4e-3}[which]
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_unet_small_forward_with_features_adapter(hip_ops_factory, dtype):
     """`features_adapter` (openaimodel3d.py:584-596) on the kernels: the plug-in features are added in place in the
