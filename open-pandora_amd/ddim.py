@@ -418,6 +418,8 @@ class DDIMSampler:
             raise NotImplementedError("quantize_x0 needs a VQ first stage; the Open-Pandora first stage is AutoencoderKL")
         if score_corrector is not None and self._fp() is not None:
             raise NotImplementedError("score_corrector sees one rank's frames only in frame-sharded mode")
+        if noise_dropout > 0.0 and self._multi_rank():
+            raise NotImplementedError("noise_dropout draws its mask from this rank's RNG: the ranks of one clip would diverge")
         self.make_schedule(ddim_num_steps=S, ddim_discretize=timestep_spacing, ddim_eta=eta, verbose=schedule_verbose)
         size = (batch_size, *shape)
         return self.ddim_sampling(conditioning, size, callback=callback, img_callback=img_callback, mask=mask,
